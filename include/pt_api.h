@@ -1,0 +1,298 @@
+/*
+ * pt_api.h - C-ABI of the MI355X path-tracing core (libptamd.so).
+ *
+ * The reference renderer (LiamTyler/PathTracer) has no plugin or FFI interface.  Its narrowest seam is
+ *     void PathTracer::Render( Scene* scene, int samplesPerPixelIteration )      src/path_tracer.hpp:14
+ * which reads the immutable Scene (src/scene.hpp:27-37) and fills PathTracer::renderedImage
+ * (src/path_tracer.hpp:18).  This header is that seam as plain C: every entry point takes plain pointers
+ * and sizes, no C++ or torch types.  A host (the reference's own C++ host, or the host in
+ * pathtracer_amd/host/) flattens its Scene into a PtSceneDesc, and the three calls
+ *     pt_upload_scene -> pt_render -> pt_readback
+ * replace the body of PathTracer::Render (src/path_tracer.cpp:158-222).
+ *
+ * Ownership: the caller owns every host array and may free it as soon as the call that received it
+ * returns.  The library owns device memory from pt_upload_scene until pt_destroy_scene.
+ * Errors: every call returns 0 on success, a PT_ERR_* code otherwise, and never throws or aborts;
+ * pt_last_error() gives a thread-local message.  (The reference's convention is bool + LOG_ERR,
+ * src/main.cpp:16,27.)
+ * Threading: calls on one PtScene are not re-entrant; one process drives one GPU.
+ * All floating point data is IEEE binary32; matrices are column-major like glm.
+ */
+#ifndef PT_API_H
+#define PT_API_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PT_API_VERSION 1u
+
+enum
+{
+    PT_OK              = 0,
+    PT_ERR_INVALID_ARG = 1, /* null pointer, bad size, struct_size/version mismatch           */
+    PT_ERR_INVALID_SCENE = 2, /* index out of range, malformed BVH, unsupported value        */
+    PT_ERR_DEVICE      = 3, /* a HIP call failed (no device, out of memory, launch failure)  */
+    PT_ERR_STATE       = 4  /* call order: readback before render, ...                       */
+};
+
+/* Byte-identical to the reference's LinearBVHNode (src/bvh.hpp:10-21): 32 bytes, alignment 4.
+ * Nodes are in depth-first pre-order: the first child of inner node i is i+1, `offset` is the index of
+ * its second child (src/bvh.cpp:180-202).  For a leaf (num_shapes > 0) `offset` is the first index of
+ * its shapes in PtSceneDesc::prims and the leaf covers [offset, offset + num_shapes). */
+typedef struct PtBvhNode
+{
+    float    aabb_min[3];
+    float    aabb_max[3];
+    int32_t  offset;
+    uint16_t num_shapes;
+    uint8_t  axis;
+    uint8_t  pad;
+} PtBvhNode;
+
+enum
+{
+    PT_PRIM_TRIANGLE = 0,
+    PT_PRIM_SPHERE   = 1
+};
+
+/* One entry of the reference's reordered shape list BVH::shapes (src/bvh.cpp:217-221).  The position of
+ * an entry in PtSceneDesc::prims is the "primitive id" every hit query reports. */
+typedef struct PtPrim
+{
+    uint32_t type;  /* PT_PRIM_*                                   */
+    uint32_t index; /* into PtSceneDesc::triangles or ::spheres    */
+} PtPrim;
+
+/* Triangle (src/shapes.hpp:57-60): three mesh-local vertex indices and the mesh they index. */
+typedef struct PtTriangle
+{
+    uint32_t i0, i1, i2;
+    uint32_t mesh;
+} PtTriangle;
+
+/* MeshInstance::data (src/resource/model.hpp:26-32, baked to world space by model.cpp:271-289).  The
+ * vertex attributes of all meshes are concatenated in PtSceneDesc::vertices/normals/tangents/uvs;
+ * vertex k of this mesh is element vertex_offset + k of each. */
+typedef struct PtMesh
+{
+    uint32_t vertex_offset;
+    uint32_t num_vertices;
+    int32_t  material;
+    uint32_t reserved;
+} PtMesh;
+
+/* Sphere (src/shapes.hpp:40-47).  world_to_local is Transform(position, rotation, radius).Inverse()
+ * (src/scene.cpp:273), column-major. */
+typedef struct PtSphere
+{
+    float   position[3];
+    float   radius;
+    float   world_to_local[16];
+    int32_t material;
+} PtSphere;
+
+/* The fields of Material the integrator reads (src/resource/material.hpp:28-34). */
+typedef struct PtMaterial
+{
+    float   albedo[3];
+    float   Ke[3];
+    int32_t albedo_texture; /* index into textures, -1 = none */
+} PtMaterial;
+
+/* Texture (src/resource/texture.hpp:16-32): RGBA8 rows exactly as stbi_load returned them (already
+ * flipped if the scene asked for it).  Texels live in PtSceneDesc::texels at texel_offset (in texels). */
+typedef struct PtTexture
+{
+    int32_t  width, height;
+    uint64_t texel_offset;
+} PtTexture;
+
+enum
+{
+    PT_LIGHT_POINT       = 0, /* src/lights.hpp:29-34 */
+    PT_LIGHT_DIRECTIONAL = 1, /* src/lights.hpp:36-41 */
+    PT_LIGHT_AREA        = 2  /* src/lights.hpp:47-52 */
+};
+
+/* One entry of Scene::lights, in that order (src/scene.hpp:29). */
+typedef struct PtLight
+{
+    uint32_t type;
+    int32_t  n_samples;    /* Light::nSamples (src/lights.hpp:24, src/scene.cpp:333-339) */
+    float    Lemit[3];
+    float    position[3];  /* point light                                               */
+    float    direction[3]; /* directional light, normalised by the host (scene.cpp:97)  */
+    int32_t  prim;         /* area light: index into prims of the emitting shape        */
+} PtLight;
+
+/* Camera (src/camera.hpp:16-32); the three direction vectors are the results of
+ * Camera::UpdateOrientationVectors (src/camera.cpp:6-14).  Angles in radians. */
+typedef struct PtCamera
+{
+    float position[3];
+    float view_dir[3];
+    float up_dir[3];
+    float right_dir[3];
+    float vfov;
+    float aspect_ratio;
+    float exposure;
+    float gamma;
+} PtCamera;
+
+/* Everything PathTracer::Render reads from Scene (src/scene.hpp:27-37). */
+typedef struct PtSceneDesc
+{
+    uint32_t struct_size; /* sizeof(PtSceneDesc) */
+    uint32_t version;     /* PT_API_VERSION      */
+
+    const PtBvhNode*  nodes;      uint64_t num_nodes;
+    const PtPrim*     prims;      uint64_t num_prims;
+    const PtTriangle* triangles;  uint64_t num_triangles;
+    const PtSphere*   spheres;    uint64_t num_spheres;
+    const PtMesh*     meshes;     uint64_t num_meshes;
+    const float*      vertices;   /* 3 floats per vertex */
+    const float*      normals;    /* 3 floats per vertex */
+    const float*      tangents;   /* 3 floats per vertex */
+    const float*      uvs;        /* 2 floats per vertex */
+    uint64_t          num_vertices;
+    const PtMaterial* materials;  uint64_t num_materials;
+    const PtTexture*  textures;   uint64_t num_textures;
+    const uint8_t*    texels;     uint64_t num_texels; /* RGBA8, 4 bytes per texel */
+    const PtLight*    lights;     uint64_t num_lights;
+
+    /* Skybox (src/resource/skybox.hpp:21-38): 6 faces in the order right, left, top, bottom, back, front
+     * (src/resource/skybox.cpp:23-28), each skybox_width * skybox_height RGBA float texels.  NULL = none,
+     * then background_radiance is the miss radiance (src/scene.cpp:386-393). */
+    const float* skybox;
+    int32_t      skybox_width, skybox_height;
+    float        background_radiance[3];
+
+    PtCamera camera;
+    int32_t  image_width, image_height; /* Scene::imageResolution */
+    int32_t  max_depth;                 /* Scene::maxDepth        */
+    int32_t  device;                    /* HIP device ordinal     */
+} PtSceneDesc;
+
+enum
+{
+    PT_RNG_PHILOX = 0, /* Philox4x32-10, key = seed, counter = (pixel, sample, draw / 4); word = draw % 4 */
+    PT_RNG_TABLE  = 1  /* draw d of sample s of pixel p = table[((p * spp_total + s) * draws + d) % len]  */
+};
+
+enum
+{
+    PT_TONEMAP_UNCHARTED2 = 0, /* what Render hard-codes (src/path_tracer.cpp:211-219)   */
+    PT_TONEMAP_REINHARD   = 1, /* src/tonemap.cpp:29-33                                  */
+    PT_TONEMAP_NONE       = 2  /* the reference's TONEMAP_AND_GAMMA NOT_IN_USE build      */
+};
+
+enum
+{
+    PT_RENDER_ACCUMULATE = 1u << 0, /* keep the film of earlier pt_render calls and add to it          */
+    PT_RENDER_PROFILE    = 1u << 1  /* bracket every kernel class with events (PtStats::kernel_ms)     */
+};
+
+typedef struct PtRenderParams
+{
+    uint32_t struct_size;      /* sizeof(PtRenderParams)                                             */
+    uint32_t flags;            /* PT_RENDER_*                                                         */
+    int32_t  spp_total;        /* Scene::numSamplesPerPixel[i]: samples per pixel of the whole image  */
+    int32_t  sample_begin;     /* this call renders samples [sample_begin, sample_end) of every pixel */
+    int32_t  sample_end;
+    uint32_t rng_mode;         /* PT_RNG_*                                                            */
+    uint64_t seed;
+    const float* sample_table; /* host pointer, PT_RNG_TABLE only                                     */
+    uint64_t sample_table_len;
+    int32_t  table_draws_per_sample;
+    int32_t  samples_per_pass; /* samples of every pixel in flight at once; 0 = choose                */
+    void*    stream;           /* hipStream_t to launch on, NULL = the library's own stream           */
+} PtRenderParams;
+
+enum
+{
+    PT_K_RAYGEN  = 0,
+    PT_K_EXTEND  = 1, /* closest-hit traversal: BVH::Intersect, src/bvh.cpp:230-268 */
+    PT_K_SHADE   = 2,
+    PT_K_CONNECT = 3, /* any-hit traversal:     BVH::Occluded,  src/bvh.cpp:270-310 */
+    PT_K_FILM    = 4,
+    PT_K_TONEMAP = 5,
+    PT_K_COUNT   = 6
+};
+
+/* Counters of everything rendered into the film since it was last cleared.  The byte model of one
+ * traced ray is 32 * nodes + 48 * triangle tests + 84 * sphere tests (closest) or 16 * sphere tests
+ * (any-hit) + 32 in + 16 out (closest) or 4 out (any-hit). */
+typedef struct PtStats
+{
+    uint64_t samples;            /* pixel samples started                       */
+    uint64_t rays_closest;       /* closest-hit rays traced                     */
+    uint64_t rays_shadow;        /* any-hit rays traced                         */
+    uint64_t nodes_closest;      /* BVH nodes fetched by closest-hit rays       */
+    uint64_t nodes_shadow;
+    uint64_t tri_tests_closest;
+    uint64_t tri_tests_shadow;
+    uint64_t sphere_tests_closest;
+    uint64_t sphere_tests_shadow;
+    uint64_t shaded_hits;
+    uint64_t launches[PT_K_COUNT];
+    double   kernel_ms[PT_K_COUNT]; /* PT_RENDER_PROFILE only, summed over launches */
+    double   render_ms;             /* host wall time of the pt_render calls, synchronised */
+} PtStats;
+
+typedef struct PtScene PtScene;
+
+/* Replaces: the Scene the reference hands to PathTracer::Render (src/main.cpp:24,35; src/scene.hpp:15-38).
+ * Validates every index and the BVH topology, copies the scene to the GPU named by desc->device in the
+ * traversal layout, and returns a handle in *out. */
+int pt_upload_scene( const PtSceneDesc* desc, PtScene** out );
+
+/* Replaces: the sample loop of PathTracer::Render (src/path_tracer.cpp:160-206): ray generation with
+ * jitter, Li (src/path_tracer.cpp:106-156), and accumulation of samples [sample_begin, sample_end) of
+ * every pixel into the film.  Returns after the work has finished on the GPU. */
+int pt_render( PtScene* scene, const PtRenderParams* params );
+
+/* Replaces: reading PathTracer::renderedImage after Render (src/path_tracer.hpp:18, src/image.cpp:102-106).
+ * rgb_linear    (nullable): W*H*3 floats, row-major r*W+c, = film sum / sample count, i.e. the image before
+ *                           the ForAllPixels pass of src/path_tracer.cpp:210-221;
+ * rgb_tonemapped(nullable): W*H*3 floats after tonemap(exposure) -> pow(1/gamma) -> clamp[0,1]
+ *                           (src/path_tracer.cpp:211-219) with the operator `tonemap` (PT_TONEMAP_*);
+ * stats         (nullable): counters since the film was last cleared. */
+int pt_readback( PtScene* scene, uint32_t tonemap, float* rgb_linear, float* rgb_tonemapped, PtStats* stats );
+
+/* Replaces: Scene::Intersect (src/scene.cpp:370-373) applied to a batch.  origins/directions: n*3 host
+ * floats.  Outputs (host, each n elements, any may be NULL): prim = index into prims of the closest hit
+ * or -1, t = hit distance (FLT_MAX on a miss), u/v = triangle barycentrics of src/intersection_tests.cpp:34-66
+ * (0 for spheres).  nodes_visited/prim_tests (nullable): per-ray counters. */
+int pt_trace_closest( PtScene* scene, uint64_t n, const float* origins, const float* directions,
+                      int32_t* prim, float* t, float* u, float* v,
+                      uint32_t* nodes_visited, uint32_t* prim_tests );
+
+/* Replaces: Scene::Occluded (src/scene.cpp:381-384) applied to a batch.  t_max: n host floats.
+ * occluded: n bytes, 1 = some shape is hit with 0 < t < t_max. */
+int pt_trace_any( PtScene* scene, uint64_t n, const float* origins, const float* directions,
+                  const float* t_max, uint8_t* occluded,
+                  uint32_t* nodes_visited, uint32_t* prim_tests );
+
+/* The film of this scene on its GPU: image_width * image_height float4 (sum r, sum g, sum b, sample
+ * count), for a host that merges the films of several GPUs with one RCCL reduce.  No counterpart in the
+ * reference (it is single-process). */
+int pt_film_device_ptr( PtScene* scene, void** device_ptr, uint64_t* bytes );
+
+/* Clears the film and the counters. */
+int pt_clear_film( PtScene* scene );
+
+/* Replaces: Scene::~Scene / BVH::~BVH (src/scene.cpp:13-19, src/bvh.cpp:7-13). */
+int pt_destroy_scene( PtScene* scene );
+
+/* Message of the last failing call on this thread ("" if none). */
+const char* pt_last_error( void );
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* PT_API_H */

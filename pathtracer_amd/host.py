@@ -1,0 +1,153 @@
+"""Binding of libpthost.so (include/pt_host.h): scene files, BVH build, procedural scenes, image output."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+from .scene import SceneData
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class HostError(RuntimeError):
+    pass
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "libpthost.so")
+        if not os.path.exists(path):
+            raise HostError(f"{path} is missing: run `make host` (or __graft_entry__.build()) first")
+        L = C.CDLL(path)
+        L.pth_scene_new.restype = C.c_void_p
+        L.pth_scene_free.argtypes = [C.c_void_p]
+        L.pth_scene_free.restype = None
+        L.pth_load_scene_file.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
+        L.pth_generate_atrium.argtypes = [C.c_void_p, C.c_uint32, C.c_int32, C.c_int32]
+        L.pth_generate_knot.argtypes = [C.c_void_p, C.c_uint32, C.c_int32]
+        L.pth_generate_soup.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_float, C.c_int32]
+        L.pth_set_image.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_float]
+        L.pth_set_max_depth.argtypes = [C.c_void_p, C.c_int32]
+        L.pth_scene_desc.argtypes = [C.c_void_p, C.c_int32, C.POINTER(abi.PtSceneDesc)]
+        L.pth_scene_info.argtypes = [C.c_void_p, C.POINTER(abi.PthSceneInfo)]
+        L.pth_build_bvh.argtypes = [C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]
+        L.pth_camera_vectors.argtypes = [C.c_void_p] * 4
+        L.pth_sphere_world_to_local.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
+        L.pth_write_image.argtypes = [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32]
+        L.pth_last_error.restype = C.c_char_p
+        _LIB = L
+    return _LIB
+
+
+def _check(rc):
+    if rc != 0:
+        raise HostError(lib().pth_last_error().decode())
+
+
+class HostScene:
+    """Owner of a C++ host scene (the role of the reference's Scene object above the boundary)."""
+
+    def __init__(self):
+        self._h = lib().pth_scene_new()
+        if not self._h:
+            raise HostError("pth_scene_new failed")
+
+    def close(self):
+        if self._h:
+            lib().pth_scene_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    @classmethod
+    def from_file(cls, filename, resource_dir):
+        s = cls()
+        if not resource_dir.endswith("/"):
+            resource_dir += "/"
+        _check(lib().pth_load_scene_file(s._h, filename.encode(), resource_dir.encode()))
+        return s
+
+    @classmethod
+    def atrium(cls, seed=1, triangles=262267, texture_size=1024):
+        s = cls()
+        _check(lib().pth_generate_atrium(s._h, seed, triangles, texture_size))
+        return s
+
+    @classmethod
+    def knot(cls, seed=2, triangles=871414):
+        s = cls()
+        _check(lib().pth_generate_knot(s._h, seed, triangles))
+        return s
+
+    @classmethod
+    def soup(cls, seed=3, triangles=20_000_000, edge=0.01, skybox_size=1024):
+        s = cls()
+        _check(lib().pth_generate_soup(s._h, seed, triangles, edge, skybox_size))
+        return s
+
+    def set_image(self, width, height, aspect_ratio=-1.0):
+        _check(lib().pth_set_image(self._h, width, height, aspect_ratio))
+
+    def set_max_depth(self, depth):
+        _check(lib().pth_set_max_depth(self._h, depth))
+
+    def desc(self, device=0):
+        """PtSceneDesc pointing into this host scene (valid while the scene is alive and unchanged)."""
+        d = abi.PtSceneDesc()
+        _check(lib().pth_scene_desc(self._h, device, C.byref(d)))
+        d._keep = self
+        return d
+
+    def info(self):
+        i = abi.PthSceneInfo()
+        _check(lib().pth_scene_info(self._h, C.byref(i)))
+        return {"spp": [i.spp[k] for k in range(i.num_spp)], "samples_per_area_light": i.samples_per_area_light,
+                "split_method": i.split_method, "output_filename": i.output_filename.decode()}
+
+    def to_data(self):
+        return SceneData.from_desc(self.desc())
+
+
+def build_bvh(boxes, split_method=abi.PTH_SPLIT_SAH):
+    """boxes: (n, 6) float32 [min xyz, max xyz] -> (nodes record array, order uint32 array)."""
+    boxes = np.ascontiguousarray(boxes, np.float32).reshape(-1, 6)
+    n = len(boxes)
+    nodes = np.zeros(2 * n - 1, abi.NODE_DTYPE)
+    order = np.zeros(n, np.uint32)
+    count = C.c_uint64(0)
+    _check(lib().pth_build_bvh(boxes.ctypes.data, n, split_method, nodes.ctypes.data, order.ctypes.data, C.byref(count)))
+    return nodes[:count.value], order
+
+
+def camera_vectors(rotation_rad):
+    r = np.ascontiguousarray(rotation_rad, np.float32)
+    view, up, right = (np.zeros(3, np.float32) for _ in range(3))
+    _check(lib().pth_camera_vectors(r.ctypes.data, view.ctypes.data, up.ctypes.data, right.ctypes.data))
+    return view, up, right
+
+
+def sphere_world_to_local(position, rotation_rad, radius):
+    p = np.ascontiguousarray(position, np.float32)
+    r = np.ascontiguousarray(rotation_rad, np.float32)
+    out = np.zeros(16, np.float32)
+    _check(lib().pth_sphere_world_to_local(p.ctypes.data, r.ctypes.data, float(radius), out.ctypes.data))
+    return out
+
+
+def write_image(filename, rgb):
+    rgb = np.ascontiguousarray(rgb, np.float32)
+    h, w = rgb.shape[:2]
+    _check(lib().pth_write_image(filename.encode(), rgb.ctypes.data, w, h))

@@ -1,0 +1,42 @@
+// Host BVH builder: produces the flattened 32-byte node array and the shape order the integrator consumes.
+#pragma once
+
+#include "hmath.hpp"
+#include "pt_api.h"
+#include <cstdint>
+#include <vector>
+
+namespace pth
+{
+
+enum class SplitMethod
+{
+    SAH,
+    Middle,
+    EqualCounts
+}; // src/bvh.hpp:26
+
+struct Aabb
+{
+    vec3 min = vec3( 3.402823466e+38f );  // src/aabb.cpp:6-10
+    vec3 max = vec3( -3.402823466e+38f );
+    void Union( const Aabb& b ) { min = vmin( min, b.min ); max = vmax( max, b.max ); } // src/aabb.cpp:18-22
+    void Union( vec3 p ) { min = vmin( min, p ); max = vmax( max, p ); }               // src/aabb.cpp:24-28
+    vec3 Centroid() const { return 0.5f * ( min + max ); }                            // src/aabb.cpp:30-33
+    int LongestDimension() const;                                                     // src/aabb.cpp:35-50
+    float SurfaceArea() const;                                                        // src/aabb.cpp:52-56
+    vec3 Offset( vec3 p ) const;                                                      // src/aabb.cpp:58-66
+};
+
+struct BvhResult
+{
+    std::vector< PtBvhNode > nodes; // depth-first pre-order, first child = index + 1
+    std::vector< uint32_t > order;  // order[k] = input index of the shape at ordered position k
+};
+
+// Builds the tree over `bounds` (one box per shape, in scene order) exactly as BVH::Build does
+// (src/bvh.cpp:204-228): same split decisions, same std::partition / std::nth_element calls, same
+// flattening.  Throws std::runtime_error if the recursion cannot make progress (all centroids equal).
+BvhResult BuildBvh( const std::vector< Aabb >& bounds, SplitMethod method );
+
+} // namespace pth

@@ -1,0 +1,352 @@
+#include "image_io.hpp"
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+
+namespace pth
+{
+
+namespace
+{
+
+    std::string Extension( const std::string& filename )
+    {
+        size_t dot = filename.find_last_of( '.' );
+        if ( dot == std::string::npos ) return "";
+        std::string e = filename.substr( dot + 1 );
+        std::transform( e.begin(), e.end(), e.begin(), []( unsigned char c ) { return std::tolower( c ); } );
+        return e;
+    }
+
+    bool ReadFile( const std::string& filename, std::vector< uint8_t >& data )
+    {
+        std::ifstream in( filename, std::ios::binary );
+        if ( !in ) return false;
+        in.seekg( 0, std::ios::end );
+        std::streamoff n = in.tellg();
+        in.seekg( 0 );
+        data.resize( static_cast< size_t >( n ) );
+        in.read( reinterpret_cast< char* >( data.data() ), n );
+        return static_cast< bool >( in );
+    }
+
+    bool ReadTga( const std::vector< uint8_t >& f, ImageRGBA8& out, std::string& error )
+    {
+        if ( f.size() < 18 ) { error = "TGA header truncated"; return false; }
+        const int idLength = f[0], colorMapType = f[1], type = f[2];
+        const int width = f[12] | ( f[13] << 8 ), height = f[14] | ( f[15] << 8 );
+        const int bpp = f[16], descriptor = f[17];
+        if ( colorMapType != 0 || !( type == 2 || type == 3 || type == 10 || type == 11 ) )
+        {
+            error = "unsupported TGA type (colour-mapped images are not handled)";
+            return false;
+        }
+        const int bytes = bpp / 8;
+        if ( !( bytes == 1 || bytes == 3 || bytes == 4 ) || width <= 0 || height <= 0 )
+        {
+            error = "unsupported TGA pixel depth";
+            return false;
+        }
+        size_t pos = 18 + static_cast< size_t >( idLength );
+        out.width  = width;
+        out.height = height;
+        out.pixels.assign( static_cast< size_t >( width ) * height * 4, 255 );
+        const bool rle = type >= 10;
+        const size_t total = static_cast< size_t >( width ) * height;
+        size_t i = 0;
+        uint8_t px[4] = { 0, 0, 0, 255 };
+        auto fetch = [&]() -> bool
+        {
+            if ( pos + bytes > f.size() ) return false;
+            if ( bytes == 1 ) { px[0] = px[1] = px[2] = f[pos]; px[3] = 255; }
+            else { px[2] = f[pos]; px[1] = f[pos + 1]; px[0] = f[pos + 2]; px[3] = bytes == 4 ? f[pos + 3] : 255; }
+            pos += bytes;
+            return true;
+        };
+        while ( i < total )
+        {
+            int run = 1;
+            bool repeat = false;
+            if ( rle )
+            {
+                if ( pos >= f.size() ) { error = "TGA data truncated"; return false; }
+                int header = f[pos++];
+                run        = ( header & 0x7f ) + 1;
+                repeat     = ( header & 0x80 ) != 0;
+                if ( repeat && !fetch() ) { error = "TGA data truncated"; return false; }
+            }
+            for ( int k = 0; k < run && i < total; ++k, ++i )
+            {
+                if ( !repeat && !fetch() ) { error = "TGA data truncated"; return false; }
+                std::memcpy( &out.pixels[4 * i], px, 4 );
+            }
+        }
+        const bool topOrigin = ( descriptor & 0x20 ) != 0;
+        if ( !topOrigin ) // stored bottom row first: bring the top row to the front
+        {
+            for ( int r = 0; r < height / 2; ++r )
+                std::swap_ranges( out.pixels.begin() + 4 * static_cast< size_t >( r ) * width,
+                                  out.pixels.begin() + 4 * static_cast< size_t >( r + 1 ) * width,
+                                  out.pixels.begin() + 4 * static_cast< size_t >( height - 1 - r ) * width );
+        }
+        return true;
+    }
+
+    bool ReadPnm( const std::vector< uint8_t >& f, ImageRGBA8& out, std::string& error )
+    {
+        size_t pos = 2;
+        auto nextInt = [&]() -> int
+        {
+            while ( pos < f.size() )
+            {
+                if ( f[pos] == '#' ) while ( pos < f.size() && f[pos] != '\n' ) ++pos;
+                else if ( std::isspace( f[pos] ) ) ++pos;
+                else break;
+            }
+            int v = 0;
+            while ( pos < f.size() && std::isdigit( f[pos] ) ) v = v * 10 + ( f[pos++] - '0' );
+            return v;
+        };
+        const int channels = f[1] == '6' ? 3 : 1;
+        const int w = nextInt(), h = nextInt(), maxv = nextInt();
+        ++pos;
+        if ( w <= 0 || h <= 0 || maxv != 255 || pos + static_cast< size_t >( w ) * h * channels > f.size() )
+        {
+            error = "unsupported or truncated PNM";
+            return false;
+        }
+        out.width  = w;
+        out.height = h;
+        out.pixels.resize( static_cast< size_t >( w ) * h * 4 );
+        for ( size_t i = 0; i < static_cast< size_t >( w ) * h; ++i )
+        {
+            for ( int c = 0; c < 3; ++c ) out.pixels[4 * i + c] = f[pos + i * channels + ( channels == 3 ? c : 0 )];
+            out.pixels[4 * i + 3] = 255;
+        }
+        return true;
+    }
+
+    bool ReadBmp( const std::vector< uint8_t >& f, ImageRGBA8& out, std::string& error )
+    {
+        auto u32 = [&]( size_t o ) { return static_cast< uint32_t >( f[o] | ( f[o + 1] << 8 ) | ( f[o + 2] << 16 ) | ( f[o + 3] << 24 ) ); };
+        if ( f.size() < 54 ) { error = "BMP header truncated"; return false; }
+        const uint32_t dataOffset = u32( 10 );
+        const int32_t w = static_cast< int32_t >( u32( 18 ) ), hRaw = static_cast< int32_t >( u32( 22 ) );
+        const int bpp = f[28] | ( f[29] << 8 );
+        const uint32_t compression = u32( 30 );
+        if ( compression != 0 || !( bpp == 24 || bpp == 32 ) || w <= 0 || hRaw == 0 )
+        {
+            error = "unsupported BMP (only uncompressed 24/32 bit)";
+            return false;
+        }
+        const int h = hRaw < 0 ? -hRaw : hRaw;
+        const size_t stride = ( static_cast< size_t >( w ) * ( bpp / 8 ) + 3 ) & ~size_t( 3 );
+        if ( dataOffset + stride * h > f.size() ) { error = "BMP data truncated"; return false; }
+        out.width  = w;
+        out.height = h;
+        out.pixels.resize( static_cast< size_t >( w ) * h * 4 );
+        for ( int r = 0; r < h; ++r )
+        {
+            const int srcRow = hRaw < 0 ? r : h - 1 - r;
+            const uint8_t* src = &f[dataOffset + stride * srcRow];
+            for ( int c = 0; c < w; ++c )
+            {
+                uint8_t* d = &out.pixels[4 * ( static_cast< size_t >( r ) * w + c )];
+                d[0] = src[c * ( bpp / 8 ) + 2];
+                d[1] = src[c * ( bpp / 8 ) + 1];
+                d[2] = src[c * ( bpp / 8 ) + 0];
+                d[3] = bpp == 32 ? src[c * 4 + 3] : 255;
+            }
+        }
+        return true;
+    }
+
+    uint32_t Crc32( const uint8_t* p, size_t n, uint32_t crc = 0 )
+    {
+        static uint32_t table[256];
+        static bool init = false;
+        if ( !init )
+        {
+            for ( uint32_t i = 0; i < 256; ++i )
+            {
+                uint32_t c = i;
+                for ( int k = 0; k < 8; ++k ) c = ( c & 1 ) ? 0xEDB88320u ^ ( c >> 1 ) : c >> 1;
+                table[i] = c;
+            }
+            init = true;
+        }
+        crc = ~crc;
+        for ( size_t i = 0; i < n; ++i ) crc = table[( crc ^ p[i] ) & 0xff] ^ ( crc >> 8 );
+        return ~crc;
+    }
+
+    void PutBE32( std::vector< uint8_t >& v, uint32_t x )
+    {
+        v.push_back( x >> 24 );
+        v.push_back( x >> 16 );
+        v.push_back( x >> 8 );
+        v.push_back( x );
+    }
+
+    void PngChunk( std::vector< uint8_t >& file, const char* tag, const std::vector< uint8_t >& data )
+    {
+        PutBE32( file, static_cast< uint32_t >( data.size() ) );
+        std::vector< uint8_t > body( tag, tag + 4 );
+        body.insert( body.end(), data.begin(), data.end() );
+        file.insert( file.end(), body.begin(), body.end() );
+        PutBE32( file, Crc32( body.data(), body.size() ) );
+    }
+
+    std::vector< uint8_t > EncodePng( const uint8_t* rgb, int w, int h )
+    {
+        std::vector< uint8_t > file = { 0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a };
+        std::vector< uint8_t > ihdr;
+        PutBE32( ihdr, w );
+        PutBE32( ihdr, h );
+        ihdr.insert( ihdr.end(), { 8, 2, 0, 0, 0 } );
+        PngChunk( file, "IHDR", ihdr );
+
+        std::vector< uint8_t > raw;
+        raw.reserve( static_cast< size_t >( h ) * ( 3 * w + 1 ) );
+        for ( int r = 0; r < h; ++r )
+        {
+            raw.push_back( 0 ); // filter: none
+            raw.insert( raw.end(), rgb + static_cast< size_t >( r ) * 3 * w, rgb + static_cast< size_t >( r + 1 ) * 3 * w );
+        }
+        std::vector< uint8_t > z = { 0x78, 0x01 };
+        uint32_t a = 1, b = 0;
+        size_t pos = 0;
+        do
+        {
+            size_t n = std::min< size_t >( 65535, raw.size() - pos );
+            z.push_back( pos + n == raw.size() ? 1 : 0 );
+            z.push_back( n & 0xff );
+            z.push_back( n >> 8 );
+            z.push_back( ~n & 0xff );
+            z.push_back( ( ~n >> 8 ) & 0xff );
+            z.insert( z.end(), raw.begin() + pos, raw.begin() + pos + n );
+            for ( size_t i = 0; i < n; ++i )
+            {
+                a = ( a + raw[pos + i] ) % 65521;
+                b = ( b + a ) % 65521;
+            }
+            pos += n;
+        } while ( pos < raw.size() );
+        PutBE32( z, ( b << 16 ) | a );
+        PngChunk( file, "IDAT", z );
+        PngChunk( file, "IEND", {} );
+        return file;
+    }
+
+} // namespace
+
+bool ReadImageRGBA8( const std::string& filename, bool flipVertically, ImageRGBA8& out, std::string& error )
+{
+    std::vector< uint8_t > f;
+    if ( !ReadFile( filename, f ) )
+    {
+        error = "Failed to load image '" + filename + "'";
+        return false;
+    }
+    bool ok = false;
+    const std::string ext = Extension( filename );
+    if ( f.size() > 2 && f[0] == 'P' && ( f[1] == '5' || f[1] == '6' ) ) ok = ReadPnm( f, out, error );
+    else if ( f.size() > 2 && f[0] == 'B' && f[1] == 'M' ) ok = ReadBmp( f, out, error );
+    else if ( ext == "tga" ) ok = ReadTga( f, out, error );
+    else error = "image format of '" + filename + "' is not decoded by this host (TGA, BMP, PPM only)";
+    if ( !ok )
+    {
+        error = "Failed to load image '" + filename + "': " + error;
+        return false;
+    }
+    if ( flipVertically )
+    {
+        const size_t row = static_cast< size_t >( out.width ) * 4;
+        for ( int r = 0; r < out.height / 2; ++r )
+            std::swap_ranges( out.pixels.begin() + row * r, out.pixels.begin() + row * ( r + 1 ),
+                              out.pixels.begin() + row * ( out.height - 1 - r ) );
+    }
+    return true;
+}
+
+std::vector< uint8_t > QuantizeRGB8( const float* rgb, int width, int height )
+{
+    std::vector< uint8_t > out( static_cast< size_t >( width ) * height * 3 );
+    for ( size_t i = 0; i < out.size(); ++i )
+    {
+        float c = rgb[i];
+        c       = c < 0.0f ? 0.0f : c;  // glm::clamp = min(max(x, 0), 1)
+        c       = 1.0f < c ? 1.0f : c;
+        out[i]  = static_cast< uint8_t >( 255.0f * c );
+    }
+    return out;
+}
+
+bool WriteImageRGB8( const std::string& filename, const uint8_t* rgb, int width, int height, std::string& error )
+{
+    const std::string ext = Extension( filename );
+    std::vector< uint8_t > file;
+    if ( ext == "png" )
+        file = EncodePng( rgb, width, height );
+    else if ( ext == "ppm" )
+    {
+        std::string header = "P6\n" + std::to_string( width ) + " " + std::to_string( height ) + "\n255\n";
+        file.assign( header.begin(), header.end() );
+        file.insert( file.end(), rgb, rgb + static_cast< size_t >( width ) * height * 3 );
+    }
+    else if ( ext == "tga" )
+    {
+        file.assign( 18, 0 );
+        file[2]  = 2;
+        file[12] = width & 0xff;
+        file[13] = width >> 8;
+        file[14] = height & 0xff;
+        file[15] = height >> 8;
+        file[16] = 24;
+        file[17] = 0x20;
+        for ( size_t i = 0; i < static_cast< size_t >( width ) * height; ++i )
+            file.insert( file.end(), { rgb[3 * i + 2], rgb[3 * i + 1], rgb[3 * i] } );
+    }
+    else if ( ext == "bmp" )
+    {
+        const size_t stride = ( static_cast< size_t >( width ) * 3 + 3 ) & ~size_t( 3 );
+        const uint32_t size = static_cast< uint32_t >( 54 + stride * height );
+        file.assign( 54, 0 );
+        file[0] = 'B';
+        file[1] = 'M';
+        auto put32 = [&]( size_t o, uint32_t v ) { for ( int k = 0; k < 4; ++k ) file[o + k] = ( v >> ( 8 * k ) ) & 0xff; };
+        put32( 2, size );
+        put32( 10, 54 );
+        put32( 14, 40 );
+        put32( 18, width );
+        put32( 22, height );
+        file[26] = 1;
+        file[28] = 24;
+        put32( 34, static_cast< uint32_t >( stride * height ) );
+        for ( int r = height - 1; r >= 0; --r )
+        {
+            size_t start = file.size();
+            for ( int c = 0; c < width; ++c )
+            {
+                const uint8_t* p = rgb + 3 * ( static_cast< size_t >( r ) * width + c );
+                file.insert( file.end(), { p[2], p[1], p[0] } );
+            }
+            file.resize( start + stride, 0 );
+        }
+    }
+    else
+    {
+        error = "Saving image as filetype '" + ext + "' is not supported";
+        return false;
+    }
+    std::ofstream out( filename, std::ios::binary );
+    if ( !out || !out.write( reinterpret_cast< const char* >( file.data() ), file.size() ) )
+    {
+        error = "Failed to write image: '" + filename + "'";
+        return false;
+    }
+    return true;
+}
+
+} // namespace pth

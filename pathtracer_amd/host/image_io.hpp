@@ -1,0 +1,30 @@
+// Image file readers / writers used by the host (textures in, rendered image out).
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace pth
+{
+
+struct ImageRGBA8
+{
+    int width = 0, height = 0;
+    std::vector< uint8_t > pixels; // 4 bytes per pixel, row 0 first
+};
+
+// Reads TGA (types 2, 3, 10, 11; 8/24/32 bit), binary PPM/PGM (P5, P6) and uncompressed 24/32-bit BMP into
+// RGBA8 with the top row first, then flips the rows if `flipVertically` - the contract of
+// stbi_load(..., 4) with stbi_set_flip_vertically_on_load as used by Texture::Load
+// (src/resource/texture.cpp:19-33).  JPEG and PNG input are not decoded here.
+bool ReadImageRGBA8( const std::string& filename, bool flipVertically, ImageRGBA8& out, std::string& error );
+
+// The reference's quantiser (src/image.cpp:57-68): 255 * clamp(c, 0, 1) truncated to uint8.
+std::vector< uint8_t > QuantizeRGB8( const float* rgb, int width, int height );
+
+// Writes 8-bit RGB as .png (stored deflate blocks), .tga, .bmp or .ppm by extension, like Image::Save
+// (src/image.cpp:43-100; .jpg is not written here).
+bool WriteImageRGB8( const std::string& filename, const uint8_t* rgb, int width, int height, std::string& error );
+
+} // namespace pth
