@@ -1,0 +1,138 @@
+"""Binding of libptamd.so, the HIP path-tracing core, through its C-ABI (include/pt_api.h).
+
+There is no CPU fallback: if the library is missing or no GPU is visible, every entry point raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libptamd.so")
+_LIB = None
+
+
+class PtError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"[pt error {code}] {message}")
+        self.code = code
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise PtError(abi.PT_ERR_DEVICE, f"{LIB_PATH} is missing: build it with `make device` "
+                                             f"(or __graft_entry__.build()); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        L.pt_last_error.restype = C.c_char_p
+        L.pt_upload_scene.argtypes = [C.POINTER(abi.PtSceneDesc), C.POINTER(C.c_void_p)]
+        L.pt_render.argtypes = [C.c_void_p, C.POINTER(abi.PtRenderParams)]
+        L.pt_readback.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(abi.PtStats)]
+        L.pt_trace_closest.argtypes = [C.c_void_p, C.c_uint64] + [C.c_void_p] * 8
+        L.pt_trace_any.argtypes = [C.c_void_p, C.c_uint64] + [C.c_void_p] * 6
+        L.pt_film_device_ptr.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+        L.pt_clear_film.argtypes = [C.c_void_p]
+        L.pt_destroy_scene.argtypes = [C.c_void_p]
+        _LIB = L
+    return _LIB
+
+
+def _check(rc):
+    if rc != 0:
+        raise PtError(rc, lib().pt_last_error().decode())
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, np.float32)
+
+
+class DeviceScene:
+    """A scene resident on one GPU (PtScene*)."""
+
+    def __init__(self, desc):
+        self._h = C.c_void_p()
+        _check(lib().pt_upload_scene(C.byref(desc), C.byref(self._h)))
+        self.width, self.height = desc.image_width, desc.image_height
+        self.max_depth = desc.max_depth
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().pt_destroy_scene(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def render(self, spp_total, sample_begin=0, sample_end=None, seed=0, table=None, table_draws_per_sample=0,
+               accumulate=False, profile=False, samples_per_pass=0, stream=None):
+        p = abi.PtRenderParams()
+        p.struct_size = C.sizeof(abi.PtRenderParams)
+        p.flags = (abi.PT_RENDER_ACCUMULATE if accumulate else 0) | (abi.PT_RENDER_PROFILE if profile else 0)
+        p.spp_total = int(spp_total)
+        p.sample_begin = int(sample_begin)
+        p.sample_end = int(spp_total if sample_end is None else sample_end)
+        p.seed = int(seed)
+        p.samples_per_pass = int(samples_per_pass)
+        p.stream = stream
+        keep = None
+        if table is not None:
+            keep = _f32(table)
+            p.rng_mode = abi.PT_RNG_TABLE
+            p.sample_table = keep.ctypes.data
+            p.sample_table_len = keep.size
+            p.table_draws_per_sample = int(table_draws_per_sample)
+        else:
+            p.rng_mode = abi.PT_RNG_PHILOX
+        _check(lib().pt_render(self._h, C.byref(p)))
+
+    def readback(self, tonemap=abi.PT_TONEMAP_UNCHARTED2, linear=True, tonemapped=True):
+        """Returns (linear (H,W,3) or None, tonemapped (H,W,3) or None, PtStats)."""
+        lin = np.zeros((self.height, self.width, 3), np.float32) if linear else None
+        tm = np.zeros((self.height, self.width, 3), np.float32) if tonemapped else None
+        stats = abi.PtStats()
+        _check(lib().pt_readback(self._h, tonemap, lin.ctypes.data if linear else None,
+                                 tm.ctypes.data if tonemapped else None, C.byref(stats)))
+        return lin, tm, stats
+
+    def stats(self):
+        stats = abi.PtStats()
+        _check(lib().pt_readback(self._h, 0, None, None, C.byref(stats)))
+        return stats
+
+    def clear_film(self):
+        _check(lib().pt_clear_film(self._h))
+
+    def film_device_ptr(self):
+        ptr, nbytes = C.c_void_p(), C.c_uint64()
+        _check(lib().pt_film_device_ptr(self._h, C.byref(ptr), C.byref(nbytes)))
+        return ptr.value, nbytes.value
+
+    def trace_closest(self, origins, dirs):
+        o, d = _f32(origins).reshape(-1, 3), _f32(dirs).reshape(-1, 3)
+        n = len(o)
+        out = {"prim": np.zeros(n, np.int32), "t": np.zeros(n, np.float32), "u": np.zeros(n, np.float32),
+               "v": np.zeros(n, np.float32), "nodes": np.zeros(n, np.uint32), "prim_tests": np.zeros(n, np.uint32)}
+        _check(lib().pt_trace_closest(self._h, n, o.ctypes.data, d.ctypes.data, out["prim"].ctypes.data,
+                                      out["t"].ctypes.data, out["u"].ctypes.data, out["v"].ctypes.data,
+                                      out["nodes"].ctypes.data, out["prim_tests"].ctypes.data))
+        return out
+
+    def trace_any(self, origins, dirs, t_max):
+        o, d, tm = _f32(origins).reshape(-1, 3), _f32(dirs).reshape(-1, 3), _f32(t_max)
+        n = len(o)
+        out = {"occluded": np.zeros(n, np.uint8), "nodes": np.zeros(n, np.uint32), "prim_tests": np.zeros(n, np.uint32)}
+        _check(lib().pt_trace_any(self._h, n, o.ctypes.data, d.ctypes.data, tm.ctypes.data, out["occluded"].ctypes.data,
+                                  out["nodes"].ctypes.data, out["prim_tests"].ctypes.data))
+        return out

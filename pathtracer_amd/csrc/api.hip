@@ -1,0 +1,748 @@
+// C-ABI of the path-tracing core (include/pt_api.h): scene validation and upload, the render loop that
+// sequences the wavefront kernels, readback, batch ray queries.
+#include "pt_api.h"
+#include "pt_device.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace ptd;
+
+namespace
+{
+
+thread_local std::string g_error;
+
+int Fail( int code, const char* fmt, ... )
+{
+    char buf[512];
+    va_list ap;
+    va_start( ap, fmt );
+    vsnprintf( buf, sizeof( buf ), fmt, ap );
+    va_end( ap );
+    g_error = buf;
+    return code;
+}
+
+#define HIP_TRY( expr )                                                                                                  \
+    do                                                                                                                   \
+    {                                                                                                                    \
+        hipError_t e_ = ( expr );                                                                                        \
+        if ( e_ != hipSuccess ) return Fail( PT_ERR_DEVICE, "%s failed: %s", #expr, hipGetErrorString( e_ ) );          \
+    } while ( 0 )
+
+// Device allocation that frees itself.
+struct DeviceBuffer
+{
+    void* ptr    = nullptr;
+    size_t bytes = 0;
+    DeviceBuffer() = default;
+    DeviceBuffer( const DeviceBuffer& ) = delete;
+    DeviceBuffer& operator=( const DeviceBuffer& ) = delete;
+    ~DeviceBuffer() { Release(); }
+    void Release()
+    {
+        if ( ptr ) (void)hipFree( ptr );
+        ptr   = nullptr;
+        bytes = 0;
+    }
+    hipError_t Allocate( size_t n )
+    {
+        Release();
+        if ( n == 0 ) return hipSuccess;
+        hipError_t e = hipMalloc( &ptr, n );
+        if ( e == hipSuccess ) bytes = n;
+        return e;
+    }
+    hipError_t Upload( const void* src, size_t n )
+    {
+        hipError_t e = Allocate( n );
+        if ( e != hipSuccess || n == 0 ) return e;
+        return hipMemcpy( ptr, src, n, hipMemcpyHostToDevice );
+    }
+    template < typename T >
+    T* As() const { return static_cast< T* >( ptr ); }
+};
+
+struct f3h
+{
+    float x, y, z;
+};
+f3h operator-( f3h a, f3h b ) { return { a.x - b.x, a.y - b.y, a.z - b.z }; }
+f3h Cross( f3h x, f3h y ) { return { x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y }; }
+float Dot( f3h a, f3h b ) { return ( a.x * b.x + a.y * b.y ) + a.z * b.z; }
+f3h Load3( const float* p ) { return { p[0], p[1], p[2] }; }
+
+constexpr float kPiHost = 3.14159265358979323846f;
+
+} // namespace
+
+struct PtScene
+{
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int gridBlocks = 2048;
+
+    // scene
+    DeviceBuffer nodes, prims, triShade, spheres, materials, textures, texels, lights, skybox;
+    SceneView view{};
+    PtCamera camera{};
+    int width = 0, height = 0, maxDepth = 0;
+    uint64_t bytesPerPathFixed = 0;
+
+    // path state
+    DeviceBuffer rayO, rayD, thr0, thr1, rad, hit, shDir, shEst, queue0, queue1, shadowQueue, counts;
+    PathBuffers paths{};
+    DeviceBuffer sampleTable;
+
+    // film and outputs
+    DeviceBuffer film, stats, linearOut, tonemappedOut;
+    bool rendered = false;
+
+    // host-side statistics
+    uint64_t samples = 0;
+    uint64_t launches[PT_K_COUNT] = {};
+    double kernelMs[PT_K_COUNT]   = {};
+    double renderMs               = 0;
+
+    struct TimedSpan
+    {
+        int kernel;
+        hipEvent_t start, stop;
+    };
+    std::vector< hipEvent_t > eventPool;
+    size_t eventsUsed = 0;
+    std::vector< TimedSpan > spans;
+
+    ~PtScene()
+    {
+        for ( hipEvent_t e : eventPool ) (void)hipEventDestroy( e );
+        if ( stream ) (void)hipStreamDestroy( stream );
+    }
+};
+
+namespace
+{
+
+// ------------------------------------------------------------------------------------------------ validation
+
+int Validate( const PtSceneDesc* d, std::vector< uint32_t >& escape )
+{
+    if ( d->struct_size != sizeof( PtSceneDesc ) ) return Fail( PT_ERR_INVALID_ARG, "PtSceneDesc::struct_size is %u, expected %zu", d->struct_size, sizeof( PtSceneDesc ) );
+    if ( d->version != PT_API_VERSION ) return Fail( PT_ERR_INVALID_ARG, "PtSceneDesc::version is %u, this library implements %u", d->version, PT_API_VERSION );
+    if ( !d->nodes || d->num_nodes == 0 || !d->prims || d->num_prims == 0 ) return Fail( PT_ERR_INVALID_SCENE, "scene has no BVH nodes or no primitives" );
+    if ( d->num_prims > kLeafFirstMask ) return Fail( PT_ERR_INVALID_SCENE, "more than %u primitives are not supported", kLeafFirstMask );
+    if ( d->num_nodes >= 0xFFFFFFFFull ) return Fail( PT_ERR_INVALID_SCENE, "too many BVH nodes" );
+    if ( d->image_width <= 0 || d->image_height <= 0 ) return Fail( PT_ERR_INVALID_SCENE, "image size %d x %d", d->image_width, d->image_height );
+    if ( static_cast< uint64_t >( d->image_width ) * d->image_height > 0x7fffffffull ) return Fail( PT_ERR_INVALID_SCENE, "image too large" );
+    if ( d->max_depth < 0 ) return Fail( PT_ERR_INVALID_SCENE, "max_depth %d", d->max_depth );
+    if ( ( d->num_triangles && !d->triangles ) || ( d->num_spheres && !d->spheres ) || ( d->num_meshes && !d->meshes ) ||
+         ( d->num_materials && !d->materials ) || ( d->num_textures && !d->textures ) || ( d->num_lights && !d->lights ) ||
+         ( d->num_texels && !d->texels ) || ( d->num_vertices && ( !d->vertices || !d->normals || !d->tangents || !d->uvs ) ) )
+        return Fail( PT_ERR_INVALID_ARG, "an array pointer is null while its count is not zero" );
+
+    for ( uint64_t i = 0; i < d->num_textures; ++i )
+    {
+        const PtTexture& t = d->textures[i];
+        if ( t.width <= 0 || t.height <= 0 || t.texel_offset + static_cast< uint64_t >( t.width ) * t.height > d->num_texels )
+            return Fail( PT_ERR_INVALID_SCENE, "texture %llu (%d x %d at %llu) lies outside the texel pool", (unsigned long long)i, t.width, t.height, (unsigned long long)t.texel_offset );
+    }
+    for ( uint64_t i = 0; i < d->num_materials; ++i )
+        if ( d->materials[i].albedo_texture < -1 || d->materials[i].albedo_texture >= static_cast< int64_t >( d->num_textures ) )
+            return Fail( PT_ERR_INVALID_SCENE, "material %llu refers to texture %d", (unsigned long long)i, d->materials[i].albedo_texture );
+    for ( uint64_t i = 0; i < d->num_meshes; ++i )
+    {
+        const PtMesh& m = d->meshes[i];
+        if ( static_cast< uint64_t >( m.vertex_offset ) + m.num_vertices > d->num_vertices ) return Fail( PT_ERR_INVALID_SCENE, "mesh %llu exceeds the vertex arrays", (unsigned long long)i );
+        if ( m.material < 0 || m.material >= static_cast< int64_t >( d->num_materials ) ) return Fail( PT_ERR_INVALID_SCENE, "mesh %llu refers to material %d", (unsigned long long)i, m.material );
+    }
+    for ( uint64_t i = 0; i < d->num_triangles; ++i )
+    {
+        const PtTriangle& t = d->triangles[i];
+        if ( t.mesh >= d->num_meshes ) return Fail( PT_ERR_INVALID_SCENE, "triangle %llu refers to mesh %u", (unsigned long long)i, t.mesh );
+        const uint32_t nv = d->meshes[t.mesh].num_vertices;
+        if ( t.i0 >= nv || t.i1 >= nv || t.i2 >= nv ) return Fail( PT_ERR_INVALID_SCENE, "triangle %llu has a vertex index outside its mesh", (unsigned long long)i );
+    }
+    for ( uint64_t i = 0; i < d->num_spheres; ++i )
+        if ( d->spheres[i].material < 0 || d->spheres[i].material >= static_cast< int64_t >( d->num_materials ) )
+            return Fail( PT_ERR_INVALID_SCENE, "sphere %llu refers to material %d", (unsigned long long)i, d->spheres[i].material );
+    for ( uint64_t i = 0; i < d->num_prims; ++i )
+    {
+        const PtPrim& p = d->prims[i];
+        if ( !( ( p.type == PT_PRIM_TRIANGLE && p.index < d->num_triangles ) || ( p.type == PT_PRIM_SPHERE && p.index < d->num_spheres ) ) )
+            return Fail( PT_ERR_INVALID_SCENE, "primitive %llu (type %u, index %u) is out of range", (unsigned long long)i, p.type, p.index );
+    }
+    for ( uint64_t i = 0; i < d->num_lights; ++i )
+    {
+        const PtLight& l = d->lights[i];
+        if ( l.type > PT_LIGHT_AREA ) return Fail( PT_ERR_INVALID_SCENE, "light %llu has unknown type %u", (unsigned long long)i, l.type );
+        if ( l.n_samples < 1 ) return Fail( PT_ERR_INVALID_SCENE, "light %llu has n_samples %d (must be >= 1)", (unsigned long long)i, l.n_samples );
+        if ( l.type == PT_LIGHT_AREA && ( l.prim < 0 || static_cast< uint64_t >( l.prim ) >= d->num_prims ) )
+            return Fail( PT_ERR_INVALID_SCENE, "area light %llu refers to primitive %d", (unsigned long long)i, l.prim );
+    }
+    if ( d->skybox && ( d->skybox_width <= 0 || d->skybox_height <= 0 ) ) return Fail( PT_ERR_INVALID_SCENE, "skybox size %d x %d", d->skybox_width, d->skybox_height );
+
+    // BVH topology: pre-order, first child at index + 1, second child inside the parent's span.  The escape
+    // index of a node is the first node after its subtree; a forward pass fills it in.
+    const uint32_t N = static_cast< uint32_t >( d->num_nodes );
+    const uint32_t unset = 0xFFFFFFFFu;
+    escape.assign( N, unset );
+    escape[0] = N;
+    for ( uint32_t i = 0; i < N; ++i )
+    {
+        const PtBvhNode& n = d->nodes[i];
+        if ( escape[i] == unset ) return Fail( PT_ERR_INVALID_SCENE, "BVH node %u is not reachable from the root", i );
+        if ( n.num_shapes > 0 )
+        {
+            if ( n.num_shapes > kMaxLeafShapes ) return Fail( PT_ERR_INVALID_SCENE, "BVH leaf %u holds %u shapes; at most %d are supported", i, n.num_shapes, kMaxLeafShapes );
+            if ( n.offset < 0 || static_cast< uint64_t >( n.offset ) + n.num_shapes > d->num_prims ) return Fail( PT_ERR_INVALID_SCENE, "BVH leaf %u covers primitives outside the list", i );
+            if ( escape[i] != i + 1 ) return Fail( PT_ERR_INVALID_SCENE, "BVH node %u: array is not in depth-first pre-order", i );
+        }
+        else
+        {
+            const int64_t second = n.offset;
+            if ( second <= static_cast< int64_t >( i ) + 1 || second >= static_cast< int64_t >( escape[i] ) || second >= N )
+                return Fail( PT_ERR_INVALID_SCENE, "BVH node %u: second child %lld is outside its subtree", i, (long long)second );
+            if ( escape[i + 1] != unset || escape[second] != unset ) return Fail( PT_ERR_INVALID_SCENE, "BVH node %u: a child has two parents", i );
+            escape[i + 1]  = static_cast< uint32_t >( second );
+            escape[second] = escape[i];
+        }
+    }
+    return PT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ upload
+
+const float* TriVertex( const PtSceneDesc* d, const float* attribute, const PtTriangle& t, uint32_t index, int stride )
+{
+    return attribute + static_cast< size_t >( stride ) * ( d->meshes[t.mesh].vertex_offset + index );
+}
+
+int Upload( PtScene* s, const PtSceneDesc* d, const std::vector< uint32_t >& escape )
+{
+    const uint32_t N = static_cast< uint32_t >( d->num_nodes );
+    const uint64_t P = d->num_prims;
+
+    std::vector< float > nodes( 8ull * N );
+    for ( uint32_t i = 0; i < N; ++i )
+    {
+        const PtBvhNode& n = d->nodes[i];
+        float* o = &nodes[8ull * i];
+        o[0] = n.aabb_min[0]; o[1] = n.aabb_min[1]; o[2] = n.aabb_min[2];
+        o[3] = n.aabb_max[0]; o[4] = n.aabb_max[1]; o[5] = n.aabb_max[2];
+        uint32_t leaf = kInnerNode;
+        if ( n.num_shapes > 0 ) leaf = static_cast< uint32_t >( n.offset ) | ( static_cast< uint32_t >( n.num_shapes - 1 ) << 28 );
+        std::memcpy( &o[6], &escape[i], 4 );
+        std::memcpy( &o[7], &leaf, 4 );
+    }
+    HIP_TRY( s->nodes.Upload( nodes.data(), nodes.size() * 4 ) );
+
+    std::vector< float > prims( 12ull * P, 0.0f ), shade( 28ull * P, 0.0f );
+    for ( uint64_t i = 0; i < P; ++i )
+    {
+        float* q = &prims[12 * i];
+        if ( d->prims[i].type == PT_PRIM_TRIANGLE )
+        {
+            const PtTriangle& t = d->triangles[d->prims[i].index];
+            f3h v0 = Load3( TriVertex( d, d->vertices, t, t.i0, 3 ) );
+            f3h e1 = Load3( TriVertex( d, d->vertices, t, t.i1, 3 ) ) - v0; // v0v1 of src/intersection_tests.cpp:37
+            f3h e2 = Load3( TriVertex( d, d->vertices, t, t.i2, 3 ) ) - v0; // v0v2 of src/intersection_tests.cpp:38
+            q[0] = v0.x; q[1] = v0.y; q[2] = v0.z;
+            uint32_t tag = kTagTriangle;
+            std::memcpy( &q[3], &tag, 4 );
+            q[4] = e1.x; q[5] = e1.y; q[6] = e1.z;
+            q[8] = e2.x; q[9] = e2.y; q[10] = e2.z;
+            float* a = &shade[28 * i];
+            const uint32_t idx[3] = { t.i0, t.i1, t.i2 };
+            for ( int k = 0; k < 3; ++k )
+            {
+                std::memcpy( a + 3 * k, TriVertex( d, d->normals, t, idx[k], 3 ), 12 );
+                std::memcpy( a + 9 + 3 * k, TriVertex( d, d->tangents, t, idx[k], 3 ), 12 );
+                std::memcpy( a + 18 + 2 * k, TriVertex( d, d->uvs, t, idx[k], 2 ), 8 );
+            }
+            int32_t material = d->meshes[t.mesh].material;
+            std::memcpy( a + 24, &material, 4 );
+        }
+        else
+        {
+            const PtSphere& sp = d->spheres[d->prims[i].index];
+            q[0] = sp.position[0]; q[1] = sp.position[1]; q[2] = sp.position[2];
+            uint32_t tag = kTagSphere, index = d->prims[i].index;
+            std::memcpy( &q[3], &tag, 4 );
+            q[4] = sp.radius;
+            std::memcpy( &q[5], &index, 4 );
+        }
+    }
+    HIP_TRY( s->prims.Upload( prims.data(), prims.size() * 4 ) );
+    HIP_TRY( s->triShade.Upload( shade.data(), shade.size() * 4 ) );
+
+    std::vector< float > spheres( 24ull * d->num_spheres, 0.0f );
+    for ( uint64_t i = 0; i < d->num_spheres; ++i )
+    {
+        const PtSphere& sp = d->spheres[i];
+        float* o = &spheres[24 * i];
+        std::memcpy( o, sp.world_to_local, 64 );
+        o[16] = sp.position[0]; o[17] = sp.position[1]; o[18] = sp.position[2]; o[19] = sp.radius;
+        std::memcpy( &o[20], &sp.material, 4 );
+    }
+    HIP_TRY( s->spheres.Upload( spheres.data(), spheres.size() * 4 ) );
+
+    std::vector< float > materials( 8ull * d->num_materials, 0.0f );
+    for ( uint64_t i = 0; i < d->num_materials; ++i )
+    {
+        const PtMaterial& m = d->materials[i];
+        float* o = &materials[8 * i];
+        o[0] = m.albedo[0]; o[1] = m.albedo[1]; o[2] = m.albedo[2];
+        std::memcpy( &o[3], &m.albedo_texture, 4 );
+        o[4] = m.Ke[0]; o[5] = m.Ke[1]; o[6] = m.Ke[2];
+    }
+    HIP_TRY( s->materials.Upload( materials.data(), materials.size() * 4 ) );
+
+    std::vector< DevTexture > textures( d->num_textures );
+    for ( uint64_t i = 0; i < d->num_textures; ++i )
+        textures[i] = DevTexture{ d->textures[i].width, d->textures[i].height, static_cast< uint32_t >( d->textures[i].texel_offset ),
+                                  static_cast< uint32_t >( d->textures[i].texel_offset >> 32 ) };
+    HIP_TRY( s->textures.Upload( textures.data(), textures.size() * sizeof( DevTexture ) ) );
+    HIP_TRY( s->texels.Upload( d->texels, d->num_texels * 4 ) );
+
+    std::vector< DevLight > lights( d->num_lights );
+    int slots = 0;
+    uint32_t areaSamples = 0;
+    for ( uint64_t i = 0; i < d->num_lights; ++i )
+    {
+        const PtLight& l = d->lights[i];
+        DevLight o;
+        std::memset( &o, 0, sizeof( o ) );
+        o.type     = l.type;
+        o.nSamples = l.n_samples;
+        std::memcpy( o.Lemit, l.Lemit, 12 );
+        if ( l.type == PT_LIGHT_POINT ) std::memcpy( o.a, l.position, 12 );
+        if ( l.type == PT_LIGHT_DIRECTIONAL ) std::memcpy( o.a, l.direction, 12 );
+        if ( l.type == PT_LIGHT_AREA )
+        {
+            o.drawOffset = areaSamples;
+            areaSamples += static_cast< uint32_t >( l.n_samples );
+            const PtPrim& p = d->prims[l.prim];
+            o.shapeType = p.type;
+            if ( p.type == PT_PRIM_TRIANGLE )
+            {
+                const PtTriangle& t = d->triangles[p.index];
+                const uint32_t idx[3] = { t.i0, t.i1, t.i2 };
+                float* vs[3] = { o.v0, o.v1, o.v2 };
+                float* ns[3] = { o.n0, o.n1, o.n2 };
+                for ( int k = 0; k < 3; ++k )
+                {
+                    std::memcpy( vs[k], TriVertex( d, d->vertices, t, idx[k], 3 ), 12 );
+                    std::memcpy( ns[k], TriVertex( d, d->normals, t, idx[k], 3 ), 12 );
+                }
+                // Triangle::Area (src/shapes.cpp:96-102) and the area pdf 1 / Area (src/shapes.cpp:113)
+                f3h c      = Cross( Load3( o.v1 ) - Load3( o.v0 ), Load3( o.v2 ) - Load3( o.v0 ) );
+                float area = 0.5f * std::sqrt( Dot( c, c ) );
+                o.invArea  = 1.0f / area;
+            }
+            else
+            {
+                const PtSphere& sp = d->spheres[p.index];
+                std::memcpy( o.a, sp.position, 12 );
+                o.radius   = sp.radius;
+                float area = 4 * kPiHost * sp.radius * sp.radius; // Sphere::Area (src/shapes.cpp:37-40)
+                o.invArea  = 1.0f / area;
+            }
+        }
+        slots += l.n_samples;
+        lights[i] = o;
+    }
+    HIP_TRY( s->lights.Upload( lights.data(), lights.size() * sizeof( DevLight ) ) );
+    if ( d->skybox ) HIP_TRY( s->skybox.Upload( d->skybox, 6ull * d->skybox_width * d->skybox_height * 16 ) );
+
+    SceneView& v    = s->view;
+    v.nodes         = s->nodes.As< float4 >();
+    v.prims         = s->prims.As< float4 >();
+    v.triShade      = s->triShade.As< float4 >();
+    v.spheres       = s->spheres.As< float4 >();
+    v.materials     = s->materials.As< float4 >();
+    v.textures      = s->textures.As< DevTexture >();
+    v.texels        = s->texels.As< uint32_t >();
+    v.lights        = s->lights.As< DevLight >();
+    v.skybox        = s->skybox.As< float4 >();
+    v.numNodes      = N;
+    v.numLights     = static_cast< uint32_t >( d->num_lights );
+    v.shadowSlots   = slots;
+    v.drawsPerBounce = static_cast< int32_t >( 2 * areaSamples + 2 );
+    v.skyboxWidth   = d->skybox_width;
+    v.skyboxHeight  = d->skybox_height;
+    std::memcpy( v.background, d->background_radiance, 12 );
+
+    s->camera   = d->camera;
+    s->width    = d->image_width;
+    s->height   = d->image_height;
+    s->maxDepth = d->max_depth;
+    // rayO, rayD, thr x2, rad, hit (16 B each), two queues + shadow queue (4 B each), shadow records 32 B per slot
+    s->bytesPerPathFixed = 6 * 16 + 3 * 4 + 32ull * static_cast< uint64_t >( slots > 0 ? slots : 1 );
+
+    const size_t pixels = static_cast< size_t >( s->width ) * s->height;
+    HIP_TRY( s->film.Allocate( pixels * 16 ) );
+    HIP_TRY( hipMemset( s->film.ptr, 0, pixels * 16 ) );
+    HIP_TRY( s->stats.Allocate( ST_COUNT * 8 ) );
+    HIP_TRY( hipMemset( s->stats.ptr, 0, ST_COUNT * 8 ) );
+    HIP_TRY( s->counts.Allocate( 2 * 4 * static_cast< size_t >( s->maxDepth > 0 ? s->maxDepth : 1 ) ) );
+    return PT_OK;
+}
+
+int EnsurePathBuffers( PtScene* s, uint64_t capacity )
+{
+    if ( s->paths.capacity >= capacity ) return PT_OK;
+    const uint64_t slots = s->view.shadowSlots > 0 ? s->view.shadowSlots : 1;
+    HIP_TRY( s->rayO.Allocate( capacity * 16 ) );
+    HIP_TRY( s->rayD.Allocate( capacity * 16 ) );
+    HIP_TRY( s->thr0.Allocate( capacity * 16 ) );
+    HIP_TRY( s->thr1.Allocate( capacity * 16 ) );
+    HIP_TRY( s->rad.Allocate( capacity * 16 ) );
+    HIP_TRY( s->hit.Allocate( capacity * 16 ) );
+    HIP_TRY( s->shDir.Allocate( capacity * slots * 16 ) );
+    HIP_TRY( s->shEst.Allocate( capacity * slots * 16 ) );
+    HIP_TRY( s->queue0.Allocate( capacity * 4 ) );
+    HIP_TRY( s->queue1.Allocate( capacity * 4 ) );
+    HIP_TRY( s->shadowQueue.Allocate( capacity * 4 ) );
+    PathBuffers& p = s->paths;
+    p.rayO        = s->rayO.As< float4 >();
+    p.rayD        = s->rayD.As< float4 >();
+    p.thr[0]      = s->thr0.As< float4 >();
+    p.thr[1]      = s->thr1.As< float4 >();
+    p.rad         = s->rad.As< float4 >();
+    p.hit         = s->hit.As< float4 >();
+    p.shDir       = s->shDir.As< float4 >();
+    p.shEst       = s->shEst.As< float4 >();
+    p.queue[0]    = s->queue0.As< uint32_t >();
+    p.queue[1]    = s->queue1.As< uint32_t >();
+    p.shadowQueue = s->shadowQueue.As< uint32_t >();
+    p.counts      = s->counts.As< uint32_t >();
+    p.capacity    = capacity;
+    return PT_OK;
+}
+
+// Camera frame of src/path_tracer.cpp:168-173, in host float arithmetic (tanf from the host's libm).
+CameraFrame MakeCameraFrame( const PtCamera& cam, int width, int height )
+{
+    auto add = []( f3h a, f3h b ) { return f3h{ a.x + b.x, a.y + b.y, a.z + b.z }; };
+    auto mul = []( f3h a, float k ) { return f3h{ a.x * k, a.y * k, a.z * k }; };
+    f3h position = Load3( cam.position ), view = Load3( cam.view_dir ), up = Load3( cam.up_dir ), right = Load3( cam.right_dir );
+    float halfHeight = std::tan( cam.vfov / 2 );
+    float halfWidth  = halfHeight * cam.aspect_ratio;
+    f3h UL = add( add( position, view ), mul( up, halfHeight ) ) - mul( right, halfWidth );
+    f3h dU = mul( right, 2 * halfWidth / width );
+    f3h dV = mul( f3h{ -up.x, -up.y, -up.z }, 2 * halfHeight / height );
+    UL     = add( UL, mul( add( dU, dV ), 0.5f ) );
+    CameraFrame f;
+    std::memcpy( f.position, &position, 12 );
+    std::memcpy( f.UL, &UL, 12 );
+    std::memcpy( f.dU, &dU, 12 );
+    std::memcpy( f.dV, &dV, 12 );
+    return f;
+}
+
+struct SpanTimer
+{
+    PtScene* s;
+    hipStream_t stream;
+    bool enabled;
+    int Begin( int kernel )
+    {
+        s->launches[kernel]++;
+        if ( !enabled ) return -1;
+        while ( s->eventPool.size() < s->eventsUsed + 2 )
+        {
+            hipEvent_t e;
+            if ( hipEventCreate( &e ) != hipSuccess ) return -1;
+            s->eventPool.push_back( e );
+        }
+        PtScene::TimedSpan span{ kernel, s->eventPool[s->eventsUsed], s->eventPool[s->eventsUsed + 1] };
+        s->eventsUsed += 2;
+        (void)hipEventRecord( span.start, stream );
+        s->spans.push_back( span );
+        return static_cast< int >( s->spans.size() ) - 1;
+    }
+    void End( int idx )
+    {
+        if ( idx >= 0 ) (void)hipEventRecord( s->spans[idx].stop, stream );
+    }
+};
+
+} // namespace
+
+extern "C" {
+
+const char* pt_last_error( void ) { return g_error.c_str(); }
+
+int pt_upload_scene( const PtSceneDesc* desc, PtScene** out )
+{
+    if ( !desc || !out ) return Fail( PT_ERR_INVALID_ARG, "pt_upload_scene: null argument" );
+    *out = nullptr;
+    std::vector< uint32_t > escape;
+    int rc = Validate( desc, escape );
+    if ( rc != PT_OK ) return rc;
+
+    int deviceCount = 0;
+    HIP_TRY( hipGetDeviceCount( &deviceCount ) );
+    if ( desc->device < 0 || desc->device >= deviceCount ) return Fail( PT_ERR_DEVICE, "device %d requested, %d GPU(s) visible", desc->device, deviceCount );
+    HIP_TRY( hipSetDevice( desc->device ) );
+
+    PtScene* s = new ( std::nothrow ) PtScene;
+    if ( !s ) return Fail( PT_ERR_DEVICE, "out of host memory" );
+    s->device = desc->device;
+    hipDeviceProp_t prop;
+    if ( hipGetDeviceProperties( &prop, desc->device ) == hipSuccess && prop.multiProcessorCount > 0 ) s->gridBlocks = prop.multiProcessorCount * 8;
+    hipError_t e = hipStreamCreate( &s->stream );
+    if ( e != hipSuccess )
+    {
+        delete s;
+        return Fail( PT_ERR_DEVICE, "hipStreamCreate failed: %s", hipGetErrorString( e ) );
+    }
+    rc = Upload( s, desc, escape );
+    if ( rc != PT_OK )
+    {
+        delete s;
+        return rc;
+    }
+    *out = s;
+    return PT_OK;
+}
+
+int pt_destroy_scene( PtScene* scene )
+{
+    if ( !scene ) return PT_OK;
+    (void)hipSetDevice( scene->device );
+    (void)hipDeviceSynchronize();
+    delete scene;
+    return PT_OK;
+}
+
+int pt_clear_film( PtScene* s )
+{
+    if ( !s ) return Fail( PT_ERR_INVALID_ARG, "pt_clear_film: null scene" );
+    HIP_TRY( hipSetDevice( s->device ) );
+    HIP_TRY( hipMemsetAsync( s->film.ptr, 0, s->film.bytes, s->stream ) );
+    HIP_TRY( hipMemsetAsync( s->stats.ptr, 0, s->stats.bytes, s->stream ) );
+    HIP_TRY( hipStreamSynchronize( s->stream ) );
+    s->samples = 0;
+    std::memset( s->launches, 0, sizeof( s->launches ) );
+    std::memset( s->kernelMs, 0, sizeof( s->kernelMs ) );
+    s->renderMs = 0;
+    s->rendered = false;
+    return PT_OK;
+}
+
+int pt_render( PtScene* s, const PtRenderParams* p )
+{
+    if ( !s || !p ) return Fail( PT_ERR_INVALID_ARG, "pt_render: null argument" );
+    if ( p->struct_size != sizeof( PtRenderParams ) ) return Fail( PT_ERR_INVALID_ARG, "PtRenderParams::struct_size is %u, expected %zu", p->struct_size, sizeof( PtRenderParams ) );
+    if ( p->sample_begin < 0 || p->sample_end < p->sample_begin || p->spp_total < 1 ) return Fail( PT_ERR_INVALID_ARG, "pt_render: bad sample range [%d, %d) of %d", p->sample_begin, p->sample_end, p->spp_total );
+    if ( p->rng_mode > PT_RNG_TABLE ) return Fail( PT_ERR_INVALID_ARG, "pt_render: unknown rng_mode %u", p->rng_mode );
+    if ( p->rng_mode == PT_RNG_TABLE && ( !p->sample_table || p->sample_table_len == 0 || p->table_draws_per_sample < 1 ) )
+        return Fail( PT_ERR_INVALID_ARG, "pt_render: PT_RNG_TABLE needs a table and table_draws_per_sample" );
+    HIP_TRY( hipSetDevice( s->device ) );
+    hipStream_t stream = p->stream ? static_cast< hipStream_t >( p->stream ) : s->stream;
+    const auto wallStart = std::chrono::steady_clock::now();
+
+    if ( !( p->flags & PT_RENDER_ACCUMULATE ) )
+    {
+        int rc = pt_clear_film( s );
+        if ( rc != PT_OK ) return rc;
+    }
+
+    const uint64_t pixels = static_cast< uint64_t >( s->width ) * s->height;
+    const int totalSamples = p->sample_end - p->sample_begin;
+    // samples of every pixel in flight at once: as many as fit 16 Mi paths and 24 GiB of path state
+    uint64_t perPass = p->samples_per_pass > 0 ? static_cast< uint64_t >( p->samples_per_pass ) : 0;
+    if ( perPass == 0 )
+    {
+        const uint64_t maxPaths = std::min< uint64_t >( 16ull << 20, ( 24ull << 30 ) / s->bytesPerPathFixed );
+        perPass = std::max< uint64_t >( 1, maxPaths / pixels );
+    }
+    if ( perPass > static_cast< uint64_t >( totalSamples ) ) perPass = totalSamples > 0 ? totalSamples : 1;
+    if ( perPass * pixels > 0x7fffffffull ) return Fail( PT_ERR_INVALID_ARG, "pt_render: %llu samples per pass of %llu pixels exceeds 2^31 paths", (unsigned long long)perPass, (unsigned long long)pixels );
+    if ( totalSamples > 0 )
+    {
+        int rc = EnsurePathBuffers( s, perPass * pixels );
+        if ( rc != PT_OK ) return rc;
+    }
+
+    RngParams rng{};
+    rng.mode       = p->rng_mode;
+    rng.seedLo     = static_cast< uint32_t >( p->seed );
+    rng.seedHi     = static_cast< uint32_t >( p->seed >> 32 );
+    rng.sppTotal   = p->spp_total;
+    rng.tableDraws = p->table_draws_per_sample;
+    if ( p->rng_mode == PT_RNG_TABLE )
+    {
+        HIP_TRY( s->sampleTable.Upload( p->sample_table, p->sample_table_len * 4 ) );
+        rng.table    = s->sampleTable.As< float >();
+        rng.tableLen = p->sample_table_len;
+    }
+
+    const CameraFrame cam = MakeCameraFrame( s->camera, s->width, s->height );
+    const LaunchCfg cfg{ stream, s->gridBlocks };
+    SpanTimer timer{ s, stream, ( p->flags & PT_RENDER_PROFILE ) != 0 };
+    uint64_t* stats = s->stats.As< uint64_t >();
+    const PathBuffers& pb = s->paths;
+
+    for ( int begin = p->sample_begin; begin < p->sample_end; begin += static_cast< int >( perPass ) )
+    {
+        const uint32_t inPass   = static_cast< uint32_t >( std::min< int >( static_cast< int >( perPass ), p->sample_end - begin ) );
+        const uint32_t numPaths = inPass * static_cast< uint32_t >( pixels );
+        HIP_TRY( hipMemsetAsync( s->counts.ptr, 0, s->counts.bytes, stream ) );
+
+        int span = timer.Begin( PT_K_RAYGEN );
+        LaunchRaygen( cfg, cam, rng, pb, s->width, s->height, static_cast< uint32_t >( begin ), numPaths );
+        timer.End( span );
+
+        if ( s->maxDepth == 0 ) HIP_TRY( hipMemsetAsync( s->rad.ptr, 0, static_cast< size_t >( numPaths ) * 16, stream ) );
+        for ( int bounce = 0; bounce < s->maxDepth; ++bounce )
+        {
+            const uint32_t* queue    = bounce == 0 ? nullptr : pb.queue[bounce & 1];
+            const uint32_t* countPtr = bounce == 0 ? nullptr : pb.counts + 2 * ( bounce - 1 );
+            span = timer.Begin( PT_K_EXTEND );
+            LaunchExtend( cfg, s->view, pb, queue, countPtr, numPaths, stats );
+            timer.End( span );
+            span = timer.Begin( PT_K_SHADE );
+            LaunchShade( cfg, s->view, rng, pb, bounce, s->maxDepth, s->width, s->height, static_cast< uint32_t >( begin ), queue, countPtr, numPaths, stats );
+            timer.End( span );
+            if ( s->view.numLights > 0 )
+            {
+                span = timer.Begin( PT_K_CONNECT );
+                LaunchConnect( cfg, s->view, pb, bounce, stats );
+                timer.End( span );
+            }
+        }
+        span = timer.Begin( PT_K_FILM );
+        LaunchFilm( cfg, pb, s->film.As< float4 >(), static_cast< uint32_t >( pixels ), inPass );
+        timer.End( span );
+        HIP_TRY( hipGetLastError() );
+        s->samples += numPaths;
+    }
+
+    HIP_TRY( hipStreamSynchronize( stream ) );
+    for ( const PtScene::TimedSpan& span : s->spans )
+    {
+        float ms = 0;
+        if ( hipEventElapsedTime( &ms, span.start, span.stop ) == hipSuccess ) s->kernelMs[span.kernel] += ms;
+    }
+    s->spans.clear();
+    s->eventsUsed = 0;
+    s->rendered   = true;
+    s->renderMs += std::chrono::duration< double, std::milli >( std::chrono::steady_clock::now() - wallStart ).count();
+    return PT_OK;
+}
+
+int pt_readback( PtScene* s, uint32_t tonemap, float* rgb_linear, float* rgb_tonemapped, PtStats* stats )
+{
+    if ( !s ) return Fail( PT_ERR_INVALID_ARG, "pt_readback: null scene" );
+    if ( tonemap > PT_TONEMAP_NONE ) return Fail( PT_ERR_INVALID_ARG, "pt_readback: unknown tonemap operator %u", tonemap );
+    if ( !s->rendered && ( rgb_linear || rgb_tonemapped ) ) return Fail( PT_ERR_STATE, "pt_readback: nothing has been rendered into the film" );
+    HIP_TRY( hipSetDevice( s->device ) );
+    const size_t pixels = static_cast< size_t >( s->width ) * s->height;
+    if ( rgb_linear || rgb_tonemapped )
+    {
+        if ( !s->linearOut.ptr ) HIP_TRY( s->linearOut.Allocate( pixels * 12 ) );
+        if ( !s->tonemappedOut.ptr ) HIP_TRY( s->tonemappedOut.Allocate( pixels * 12 ) );
+        const LaunchCfg cfg{ s->stream, s->gridBlocks };
+        s->launches[PT_K_TONEMAP]++;
+        LaunchTonemap( cfg, s->film.As< float4 >(), rgb_linear ? s->linearOut.As< float >() : nullptr,
+                       rgb_tonemapped ? s->tonemappedOut.As< float >() : nullptr, static_cast< uint32_t >( pixels ), s->camera.exposure,
+                       s->camera.gamma, tonemap );
+        HIP_TRY( hipGetLastError() );
+        if ( rgb_linear ) HIP_TRY( hipMemcpyAsync( rgb_linear, s->linearOut.ptr, pixels * 12, hipMemcpyDeviceToHost, s->stream ) );
+        if ( rgb_tonemapped ) HIP_TRY( hipMemcpyAsync( rgb_tonemapped, s->tonemappedOut.ptr, pixels * 12, hipMemcpyDeviceToHost, s->stream ) );
+        HIP_TRY( hipStreamSynchronize( s->stream ) );
+    }
+    if ( stats )
+    {
+        uint64_t dev[ST_COUNT];
+        HIP_TRY( hipMemcpy( dev, s->stats.ptr, sizeof( dev ), hipMemcpyDeviceToHost ) );
+        std::memset( stats, 0, sizeof( *stats ) );
+        stats->samples              = s->samples;
+        stats->rays_closest         = dev[ST_RAYS_CLOSEST];
+        stats->rays_shadow          = dev[ST_RAYS_SHADOW];
+        stats->nodes_closest        = dev[ST_NODES_CLOSEST];
+        stats->nodes_shadow         = dev[ST_NODES_SHADOW];
+        stats->tri_tests_closest    = dev[ST_TRI_CLOSEST];
+        stats->tri_tests_shadow     = dev[ST_TRI_SHADOW];
+        stats->sphere_tests_closest = dev[ST_SPH_CLOSEST];
+        stats->sphere_tests_shadow  = dev[ST_SPH_SHADOW];
+        stats->shaded_hits          = dev[ST_SHADED];
+        std::memcpy( stats->launches, s->launches, sizeof( s->launches ) );
+        std::memcpy( stats->kernel_ms, s->kernelMs, sizeof( s->kernelMs ) );
+        stats->render_ms = s->renderMs;
+    }
+    return PT_OK;
+}
+
+int pt_film_device_ptr( PtScene* s, void** device_ptr, uint64_t* bytes )
+{
+    if ( !s || !device_ptr ) return Fail( PT_ERR_INVALID_ARG, "pt_film_device_ptr: null argument" );
+    *device_ptr = s->film.ptr;
+    if ( bytes ) *bytes = s->film.bytes;
+    s->rendered = true; // the caller may fill the film itself (merged films of several GPUs)
+    return PT_OK;
+}
+
+int pt_trace_closest( PtScene* s, uint64_t n, const float* origins, const float* directions, int32_t* prim, float* t, float* u, float* v,
+                      uint32_t* nodes_visited, uint32_t* prim_tests )
+{
+    if ( !s || ( n && ( !origins || !directions ) ) ) return Fail( PT_ERR_INVALID_ARG, "pt_trace_closest: null argument" );
+    if ( n == 0 ) return PT_OK;
+    HIP_TRY( hipSetDevice( s->device ) );
+    DeviceBuffer dO, dD, dPrim, dT, dU, dV, dN, dP;
+    HIP_TRY( dO.Upload( origins, n * 12 ) );
+    HIP_TRY( dD.Upload( directions, n * 12 ) );
+    HIP_TRY( dPrim.Allocate( n * 4 ) );
+    HIP_TRY( dT.Allocate( n * 4 ) );
+    HIP_TRY( dU.Allocate( n * 4 ) );
+    HIP_TRY( dV.Allocate( n * 4 ) );
+    HIP_TRY( dN.Allocate( n * 4 ) );
+    HIP_TRY( dP.Allocate( n * 4 ) );
+    const LaunchCfg cfg{ s->stream, s->gridBlocks };
+    LaunchTraceClosest( cfg, s->view, n, dO.As< float >(), dD.As< float >(), dPrim.As< int32_t >(), dT.As< float >(), dU.As< float >(),
+                        dV.As< float >(), dN.As< uint32_t >(), dP.As< uint32_t >() );
+    HIP_TRY( hipGetLastError() );
+    HIP_TRY( hipStreamSynchronize( s->stream ) );
+    if ( prim ) HIP_TRY( hipMemcpy( prim, dPrim.ptr, n * 4, hipMemcpyDeviceToHost ) );
+    if ( t ) HIP_TRY( hipMemcpy( t, dT.ptr, n * 4, hipMemcpyDeviceToHost ) );
+    if ( u ) HIP_TRY( hipMemcpy( u, dU.ptr, n * 4, hipMemcpyDeviceToHost ) );
+    if ( v ) HIP_TRY( hipMemcpy( v, dV.ptr, n * 4, hipMemcpyDeviceToHost ) );
+    if ( nodes_visited ) HIP_TRY( hipMemcpy( nodes_visited, dN.ptr, n * 4, hipMemcpyDeviceToHost ) );
+    if ( prim_tests ) HIP_TRY( hipMemcpy( prim_tests, dP.ptr, n * 4, hipMemcpyDeviceToHost ) );
+    return PT_OK;
+}
+
+int pt_trace_any( PtScene* s, uint64_t n, const float* origins, const float* directions, const float* t_max, uint8_t* occluded,
+                  uint32_t* nodes_visited, uint32_t* prim_tests )
+{
+    if ( !s || ( n && ( !origins || !directions || !t_max || !occluded ) ) ) return Fail( PT_ERR_INVALID_ARG, "pt_trace_any: null argument" );
+    if ( n == 0 ) return PT_OK;
+    HIP_TRY( hipSetDevice( s->device ) );
+    DeviceBuffer dO, dD, dT, dOcc, dN, dP;
+    HIP_TRY( dO.Upload( origins, n * 12 ) );
+    HIP_TRY( dD.Upload( directions, n * 12 ) );
+    HIP_TRY( dT.Upload( t_max, n * 4 ) );
+    HIP_TRY( dOcc.Allocate( n ) );
+    HIP_TRY( dN.Allocate( n * 4 ) );
+    HIP_TRY( dP.Allocate( n * 4 ) );
+    const LaunchCfg cfg{ s->stream, s->gridBlocks };
+    LaunchTraceAny( cfg, s->view, n, dO.As< float >(), dD.As< float >(), dT.As< float >(), dOcc.As< uint8_t >(), dN.As< uint32_t >(), dP.As< uint32_t >() );
+    HIP_TRY( hipGetLastError() );
+    HIP_TRY( hipStreamSynchronize( s->stream ) );
+    HIP_TRY( hipMemcpy( occluded, dOcc.ptr, n, hipMemcpyDeviceToHost ) );
+    if ( nodes_visited ) HIP_TRY( hipMemcpy( nodes_visited, dN.ptr, n * 4, hipMemcpyDeviceToHost ) );
+    if ( prim_tests ) HIP_TRY( hipMemcpy( prim_tests, dP.ptr, n * 4, hipMemcpyDeviceToHost ) );
+    return PT_OK;
+}
+
+} // extern "C"

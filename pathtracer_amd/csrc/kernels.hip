@@ -1,0 +1,840 @@
+// Wavefront path-tracing kernels for gfx950 (MI355X, wave64).
+//
+// One kernel per stage of the reference's Li loop (src/path_tracer.cpp:106-156), each a grid-stride pass
+// over a queue of path ids:
+//   raygen   primary rays with anti-aliasing jitter                    (path_tracer.cpp:183-189)
+//   extend   closest-hit BVH traversal                                 (bvh.cpp:230-268)
+//   shade    miss radiance, hit attributes, emission, albedo / texture, light sampling, BRDF sampling,
+//            throughput update, queue compaction                       (path_tracer.cpp:115-152)
+//   connect  any-hit traversal of the shadow rays + direct light sum    (bvh.cpp:270-310, path_tracer.cpp:90-104)
+//   film     per-pixel accumulation in sample order                    (path_tracer.cpp:185-193)
+//   tonemap  Uncharted2 / Reinhard, gamma, clamp                       (path_tracer.cpp:211-219)
+//
+// Arithmetic contract: binary32 in the reference's operation order, compiled with -ffp-contract=off and
+// without fast-math, IEEE division and square root (sqrtf; __fsqrt_rn is the 1-ulp native instruction),
+// comparisons instead of min/max in the slab test, so that hit primitives and distances equal the CPU's
+// bit for bit.
+//
+// Traversal: the node array is in depth-first pre-order with the first child at index + 1, and the
+// reference always descends into the first child first.  For that fixed order the node to visit after a
+// subtree is known statically, so every node carries an escape index (the pre-order successor of its
+// subtree) and the traversal needs no stack: hit inner -> index + 1, miss or leaf done -> escape.  The
+// visit sequence is exactly the reference's stack sequence, with no per-lane stack in LDS or scratch.
+#include "pt_device.h"
+#include "pt_api.h"
+#include "pt_sincosf.h"
+
+#include <float.h>
+
+namespace ptd
+{
+
+// ------------------------------------------------------------------------------------------------ vectors
+struct f3
+{
+    float x, y, z;
+};
+
+__device__ __forceinline__ f3 F3( float x, float y, float z ) { return f3{ x, y, z }; }
+__device__ __forceinline__ f3 F3( float4 v ) { return f3{ v.x, v.y, v.z }; }
+__device__ __forceinline__ f3 F3( const float* p ) { return f3{ p[0], p[1], p[2] }; }
+__device__ __forceinline__ f3 operator+( f3 a, f3 b ) { return f3{ a.x + b.x, a.y + b.y, a.z + b.z }; }
+__device__ __forceinline__ f3 operator-( f3 a, f3 b ) { return f3{ a.x - b.x, a.y - b.y, a.z - b.z }; }
+__device__ __forceinline__ f3 operator*( f3 a, f3 b ) { return f3{ a.x * b.x, a.y * b.y, a.z * b.z }; }
+__device__ __forceinline__ f3 operator*( f3 a, float s ) { return f3{ a.x * s, a.y * s, a.z * s }; }
+__device__ __forceinline__ f3 operator/( f3 a, float s ) { return f3{ a.x / s, a.y / s, a.z / s }; }
+__device__ __forceinline__ f3 operator-( f3 a ) { return f3{ -a.x, -a.y, -a.z }; }
+__device__ __forceinline__ bool IsZero( f3 a ) { return a.x == 0.0f && a.y == 0.0f && a.z == 0.0f; }
+// glm semantics (glm/detail/func_geometric.inl): dot = (x + y) + z of the products, normalize = v * (1 / sqrt(dot))
+__device__ __forceinline__ float Dot( f3 a, f3 b ) { f3 t = a * b; return t.x + t.y + t.z; }
+__device__ __forceinline__ f3 Cross( f3 x, f3 y ) { return f3{ x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y }; }
+__device__ __forceinline__ float Length( f3 a ) { return sqrtf( Dot( a, a ) ); }
+__device__ __forceinline__ f3 Normalize( f3 a ) { return a * ( 1.0f / sqrtf( Dot( a, a ) ) ); }
+__device__ __forceinline__ float AbsDot( f3 a, f3 b ) { return fabsf( Dot( a, b ) ); }
+__device__ __forceinline__ float Max0( float x ) { return 0.0f < x ? x : 0.0f; } // std::max( 0.f, x )
+__device__ __forceinline__ float4 F4( f3 a, float w ) { return make_float4( a.x, a.y, a.z, w ); }
+
+constexpr float kPi      = 3.14159265358979323846f; // src/math.hpp:9-11
+constexpr float kEpsilon = 0.00001f;                // src/path_tracer.cpp:16
+
+// std::cos / std::sin of a float in the reference: the host C library's sincosf, reproduced exactly
+__device__ __forceinline__ void SinCosF( float x, float* s, float* c ) { SinCosLibm( x, s, c ); }
+
+// ------------------------------------------------------------------------------------------------ counters
+struct Counters
+{
+    uint32_t rays = 0, nodes = 0, tris = 0, spheres = 0, shaded = 0;
+};
+
+__device__ __forceinline__ uint32_t WaveSum( uint32_t v )
+{
+    for ( int off = 32; off > 0; off >>= 1 ) v += __shfl_down( v, off, 64 );
+    return v;
+}
+
+// One atomic per wave and counter.  Called by every lane of the wave at the end of a kernel.
+__device__ __forceinline__ void FlushCounter( uint64_t* stats, int slot, uint32_t v )
+{
+    uint32_t sum = WaveSum( v );
+    if ( ( threadIdx.x & 63 ) == 0 && sum ) atomicAdd( reinterpret_cast< unsigned long long* >( stats + slot ), static_cast< unsigned long long >( sum ) );
+}
+
+// ------------------------------------------------------------------------------------------------ primitive tests
+
+// intersect::RayTriangle (src/intersection_tests.cpp:34-66) on {v0, v1 - v0, v2 - v0}
+__device__ __forceinline__ bool RayTriangle( f3 o, f3 d, f3 v0, f3 v0v1, f3 v0v2, float maxT, float* t, float* u, float* v )
+{
+    f3 pvec   = Cross( d, v0v2 );
+    float det = Dot( v0v1, pvec );
+    if ( static_cast< double >( fabsf( det ) ) < 0.000000001 ) return false;
+    float invDet = 1.0f / det;
+    f3 tvec      = o - v0;
+    *u           = Dot( tvec, pvec ) * invDet;
+    if ( *u < 0 || *u > 1 ) return false;
+    f3 qvec = Cross( tvec, v0v1 );
+    *v      = Dot( d, qvec ) * invDet;
+    if ( *v < 0 || *u + *v > 1 ) return false;
+    *t = Dot( v0v2, qvec ) * invDet;
+    return *t < maxT && *t > 0;
+}
+
+// intersect::RaySphere (src/intersection_tests.cpp:10-31)
+__device__ __forceinline__ bool RaySphere( f3 o, f3 d, f3 centre, float radius, float maxT, float* t )
+{
+    f3 OC      = o - centre;
+    float a    = Dot( d, d );
+    float b    = 2 * Dot( OC, d );
+    float c    = Dot( OC, OC ) - radius * radius;
+    float disc = b * b - 4 * a * c;
+    if ( disc < 0 ) return false;
+    float sq = sqrtf( disc );
+    *t       = ( -b - sq ) / ( 2 * a );
+    if ( *t < 0 ) *t = ( -b + sq ) / ( 2 * a );
+    return *t < maxT && *t > 0;
+}
+
+// glm mat4 * vec4 rows 0..2 (glm/detail/type_mat4x4.inl:561-572): (m0 * x + m1 * y) + (m2 * z + m3 * w)
+__device__ __forceinline__ f3 MatMul( float4 c0, float4 c1, float4 c2, float4 c3, f3 p, float w )
+{
+    return f3{ ( c0.x * p.x + c1.x * p.y ) + ( c2.x * p.z + c3.x * w ),
+               ( c0.y * p.x + c1.y * p.y ) + ( c2.y * p.z + c3.y * w ),
+               ( c0.z * p.x + c1.z * p.y ) + ( c2.z * p.z + c3.z * w ) };
+}
+
+// intersect::RayAABBFastest (src/intersection_tests.cpp:91-110): comparisons and selects only, so that a
+// NaN slab value behaves as on the CPU.
+__device__ __forceinline__ bool RayBox( f3 o, f3 inv, bool nx, bool ny, bool nz, float4 a, float4 b, float maxT )
+{
+    float tMin  = ( ( nx ? a.w : a.x ) - o.x ) * inv.x;
+    float tMax  = ( ( nx ? a.x : a.w ) - o.x ) * inv.x;
+    float tyMin = ( ( ny ? b.x : a.y ) - o.y ) * inv.y;
+    float tyMax = ( ( ny ? a.y : b.x ) - o.y ) * inv.y;
+    if ( tMin > tyMax || tyMin > tMax ) return false;
+    if ( tyMin > tMin ) tMin = tyMin;
+    if ( tyMax < tMax ) tMax = tyMax;
+    float tzMin = ( ( nz ? b.y : a.z ) - o.z ) * inv.z;
+    float tzMax = ( ( nz ? a.z : b.y ) - o.z ) * inv.z;
+    if ( tMin > tzMax || tzMin > tMax ) return false;
+    if ( tzMin > tMin ) tMin = tzMin;
+    if ( tzMax < tMax ) tMax = tzMax;
+    return ( tMin < maxT ) && ( tMax > 0 );
+}
+
+struct HitRecord
+{
+    float t, u, v;
+    int prim;
+};
+
+// BVH::Intersect (src/bvh.cpp:230-268) + Triangle::Intersect / Sphere::Intersect acceptance
+// (src/shapes.cpp:117-123, 52-61).  Closest hit; the first primitive reaching a given t keeps it (strict <).
+__device__ __forceinline__ HitRecord TraceClosest( const SceneView& sv, f3 o, f3 d, Counters& cnt )
+{
+    HitRecord h{ FLT_MAX, 0.0f, 0.0f, -1 };
+    const f3 inv  = F3( 1.0f / d.x, 1.0f / d.y, 1.0f / d.z );
+    const bool nx = inv.x < 0, ny = inv.y < 0, nz = inv.z < 0;
+    const uint32_t end = sv.numNodes;
+    uint32_t node = 0;
+    while ( node != end )
+    {
+        const float4 a = sv.nodes[2 * node], b = sv.nodes[2 * node + 1];
+        cnt.nodes++;
+        const uint32_t escape = __float_as_uint( b.z ), leaf = __float_as_uint( b.w );
+        if ( !RayBox( o, inv, nx, ny, nz, a, b, h.t ) )
+        {
+            node = escape;
+            continue;
+        }
+        if ( leaf == kInnerNode )
+        {
+            node = node + 1;
+            continue;
+        }
+        const uint32_t first = leaf & kLeafFirstMask, count = ( leaf >> 28 ) + 1;
+        for ( uint32_t k = 0; k < count; ++k )
+        {
+            const uint32_t prim = first + k;
+            const float4 q0 = sv.prims[3 * prim], q1 = sv.prims[3 * prim + 1];
+            float t, u = 0.0f, v = 0.0f;
+            bool hit;
+            if ( __float_as_uint( q0.w ) == kTagTriangle )
+            {
+                const float4 q2 = sv.prims[3 * prim + 2];
+                cnt.tris++;
+                hit = RayTriangle( o, d, F3( q0 ), F3( q1 ), F3( q2 ), h.t, &t, &u, &v );
+            }
+            else
+            {
+                // closest-hit sphere test runs in the sphere's local space against the unit sphere
+                const float4* s = sv.spheres + 6 * __float_as_uint( q1.y );
+                const float4 c0 = s[0], c1 = s[1], c2 = s[2], c3 = s[3];
+                cnt.spheres++;
+                f3 lo = MatMul( c0, c1, c2, c3, o, 1.0f );
+                f3 ld = MatMul( c0, c1, c2, c3, d, 0.0f );
+                hit   = RaySphere( lo, ld, F3( 0.0f, 0.0f, 0.0f ), 1.0f, h.t, &t );
+            }
+            if ( hit )
+            {
+                h.t    = t;
+                h.u    = u;
+                h.v    = v;
+                h.prim = static_cast< int >( prim );
+            }
+        }
+        node = escape;
+    }
+    return h;
+}
+
+// BVH::Occluded (src/bvh.cpp:270-310) + TestIfHit (src/shapes.cpp:78-82, 136-141): spheres in world space.
+__device__ __forceinline__ bool TraceAny( const SceneView& sv, f3 o, f3 d, float tMax, Counters& cnt )
+{
+    const f3 inv  = F3( 1.0f / d.x, 1.0f / d.y, 1.0f / d.z );
+    const bool nx = inv.x < 0, ny = inv.y < 0, nz = inv.z < 0;
+    const uint32_t end = sv.numNodes;
+    uint32_t node = 0;
+    while ( node != end )
+    {
+        const float4 a = sv.nodes[2 * node], b = sv.nodes[2 * node + 1];
+        cnt.nodes++;
+        const uint32_t escape = __float_as_uint( b.z ), leaf = __float_as_uint( b.w );
+        if ( !RayBox( o, inv, nx, ny, nz, a, b, tMax ) )
+        {
+            node = escape;
+            continue;
+        }
+        if ( leaf == kInnerNode )
+        {
+            node = node + 1;
+            continue;
+        }
+        const uint32_t first = leaf & kLeafFirstMask, count = ( leaf >> 28 ) + 1;
+        for ( uint32_t k = 0; k < count; ++k )
+        {
+            const uint32_t prim = first + k;
+            const float4 q0 = sv.prims[3 * prim], q1 = sv.prims[3 * prim + 1];
+            float t, u, v;
+            if ( __float_as_uint( q0.w ) == kTagTriangle )
+            {
+                const float4 q2 = sv.prims[3 * prim + 2];
+                cnt.tris++;
+                if ( RayTriangle( o, d, F3( q0 ), F3( q1 ), F3( q2 ), tMax, &t, &u, &v ) ) return true;
+            }
+            else
+            {
+                cnt.spheres++;
+                if ( RaySphere( o, d, F3( q0 ), q1.x, tMax, &t ) ) return true;
+            }
+        }
+        node = escape;
+    }
+    return false;
+}
+
+// ------------------------------------------------------------------------------------------------ random numbers
+
+// Philox4x32-10 (Salmon et al., SC'11).
+__device__ __forceinline__ void Philox( uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4] )
+{
+#pragma unroll
+    for ( int round = 0; round < 10; ++round )
+    {
+        uint32_t hi0 = __umulhi( 0xD2511F53u, c0 ), lo0 = 0xD2511F53u * c0;
+        uint32_t hi1 = __umulhi( 0xCD9E8D57u, c2 ), lo1 = 0xCD9E8D57u * c2;
+        uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// Draws d and d + 1 of (pixel, sample), d even: the stand-in for two consecutive Random::Rand() calls
+// (src/utils/random.cpp:9-16).  Both lie in one Philox block because 4 divides the block size.
+__device__ __forceinline__ void DrawPair( const RngParams& rng, uint32_t pixel, uint32_t sample, uint32_t d, float* first, float* second )
+{
+    if ( rng.mode == PT_RNG_TABLE )
+    {
+        uint64_t base = ( static_cast< uint64_t >( pixel ) * static_cast< uint64_t >( rng.sppTotal ) + sample ) * static_cast< uint64_t >( rng.tableDraws );
+        *first  = rng.table[( base + d ) % rng.tableLen];
+        *second = rng.table[( base + d + 1 ) % rng.tableLen];
+        return;
+    }
+    uint32_t w[4];
+    Philox( pixel, sample, d >> 2, 0u, rng.seedLo, rng.seedHi, w );
+    const uint32_t a = ( d & 2u ) ? w[2] : w[0], b = ( d & 2u ) ? w[3] : w[1];
+    *first  = static_cast< float >( a >> 8 ) * ( 1.0f / 16777216.0f );
+    *second = static_cast< float >( b >> 8 ) * ( 1.0f / 16777216.0f );
+}
+
+// ------------------------------------------------------------------------------------------------ sampling
+
+// ConcentricSampleDisk / CosineSampleHemisphere (src/sampling.cpp:15-38, 48-53)
+__device__ __forceinline__ f3 CosineSampleHemisphere( float u1, float u2 )
+{
+    u1 = 2 * u1 - 1;
+    u2 = 2 * u2 - 1;
+    float dx = 0.0f, dy = 0.0f;
+    if ( !( u1 == 0 && u2 == 0 ) )
+    {
+        float theta, r = 1.0f;
+        if ( u1 * u1 > u2 * u2 )
+        {
+            r *= u1;
+            theta = ( kPi / 4 ) * ( u2 / u1 );
+        }
+        else
+        {
+            r *= u2;
+            theta = ( kPi / 2 ) - ( kPi / 4 ) * ( u1 / u2 );
+        }
+        float s, c;
+        SinCosF( theta, &s, &c );
+        dx = r * c;
+        dy = r * s;
+    }
+    float z = sqrtf( Max0( 1 - dx * dx - dy * dy ) );
+    return F3( dx, dy, z );
+}
+
+// UniformSampleSphere (src/sampling.cpp:55-61)
+__device__ __forceinline__ f3 UniformSampleSphere( float u1, float u2 )
+{
+    float z     = 1 - 2 * u1;
+    float r     = sqrtf( Max0( 1 - z * z ) );
+    float theta = 2 * kPi * u2;
+    float s, c;
+    SinCosF( theta, &s, &c );
+    return F3( r * c, r * s, z );
+}
+
+// ------------------------------------------------------------------------------------------------ textures / environment
+
+// Texture::GetPixel (src/resource/texture.cpp:49-66), rgb only
+__device__ __forceinline__ f3 TextureFetch( const SceneView& sv, int tex, float u, float v )
+{
+    const DevTexture t = sv.textures[tex];
+    u = fmodf( u, 1.0f );
+    u = u < 0 ? u + 1 : u;
+    v = fmodf( v, 1.0f );
+    v = v < 0 ? v + 1 : v;
+    int w = static_cast< int >( u * t.width );
+    int h = static_cast< int >( v * t.height );
+    if ( t.width - 1 < w ) w = t.width - 1;
+    if ( t.height - 1 < h ) h = t.height - 1;
+    const uint64_t offset = ( static_cast< uint64_t >( t.offsetHi ) << 32 | t.offsetLo ) + static_cast< uint64_t >( h * t.width + w );
+    const uint32_t px = sv.texels[offset];
+    const float k = 1.0f / 255.0f;
+    return F3( k * static_cast< float >( px & 0xffu ), k * static_cast< float >( ( px >> 8 ) & 0xffu ), k * static_cast< float >( ( px >> 16 ) & 0xffu ) );
+}
+
+// Scene::LEnvironment (src/scene.cpp:386-393) with Skybox::GetPixel( ray ) (src/resource/skybox.cpp:84-118)
+__device__ __forceinline__ f3 Environment( const SceneView& sv, f3 v )
+{
+    if ( !sv.skybox ) return F3( sv.background );
+    f3 a = F3( fabsf( v.x ), fabsf( v.y ), fabsf( v.z ) );
+    int face;
+    float ma, ux, uy;
+    if ( a.z >= a.x && a.z >= a.y )
+    {
+        face = v.z < 0.0f ? 5 : 4;
+        ma   = 0.5f / a.z;
+        ux   = v.z < 0.0f ? -v.x : v.x;
+        uy   = v.y;
+    }
+    else if ( a.y >= a.x )
+    {
+        face = v.y < 0.0f ? 3 : 2;
+        ma   = 0.5f / a.y;
+        ux   = v.x;
+        uy   = -v.z;
+    }
+    else
+    {
+        face = v.x < 0.0f ? 1 : 0;
+        ma   = 0.5f / a.x;
+        ux   = v.x < 0.0f ? v.z : -v.z;
+        uy   = v.y;
+    }
+    ux = ux * ma + 0.5f;
+    uy = uy * ma + 0.5f;
+    int w = static_cast< int >( ux * sv.skyboxWidth );
+    int h = static_cast< int >( uy * sv.skyboxHeight );
+    if ( sv.skyboxWidth - 1 < w ) w = sv.skyboxWidth - 1;
+    if ( sv.skyboxHeight - 1 < h ) h = sv.skyboxHeight - 1;
+    const size_t idx = ( static_cast< size_t >( face ) * sv.skyboxHeight + h ) * sv.skyboxWidth + w;
+    return F3( sv.skybox[idx] );
+}
+
+// ------------------------------------------------------------------------------------------------ kernels
+
+constexpr int kBlock = 256;
+
+// Primary rays: pixel position, jitter, normalised direction (src/path_tracer.cpp:183-189,
+// src/anti_aliasing.cpp:89-92).  Path id = local sample * pixels + pixel.
+__global__ __launch_bounds__( kBlock ) void RaygenKernel( CameraFrame cam, RngParams rng, PathBuffers pb, uint32_t width,
+                                                         uint32_t height, uint32_t sampleBegin, uint32_t numPaths )
+{
+    const uint32_t numPixels = width * height;
+    for ( uint32_t p = blockIdx.x * kBlock + threadIdx.x; p < numPaths; p += gridDim.x * kBlock )
+    {
+        const uint32_t pixel = p % numPixels, sample = sampleBegin + p / numPixels;
+        const uint32_t row = pixel / width, col = pixel % width;
+        const f3 position = F3( cam.position ), UL = F3( cam.UL ), dU = F3( cam.dU ), dV = F3( cam.dV );
+        f3 imagePlanePos = UL + dV * static_cast< float >( row ) + dU * static_cast< float >( col );
+        // RandFloat( -0.5f, 0.5f ) = Rand() * ( h - l ) + l (src/utils/random.cpp:18-21).  The reference as
+        // built by g++ evaluates the dV factor of `c + R() * dU + R() * dV` first: draw 0 scales dV.
+        float r0, r1;
+        DrawPair( rng, pixel, sample, 0u, &r0, &r1 );
+        const float jv = r0 * ( 0.5f - -0.5f ) + -0.5f;
+        const float ju = r1 * ( 0.5f - -0.5f ) + -0.5f;
+        f3 aa  = imagePlanePos + dU * ju + dV * jv;
+        f3 dir = Normalize( aa - position );
+        pb.rayO[p]   = F4( position, 0.0f );
+        pb.rayD[p]   = F4( dir, 0.0f );
+        pb.thr[0][p] = make_float4( 1.0f, 1.0f, 1.0f, 0.0f );
+    }
+}
+
+__global__ __launch_bounds__( kBlock ) void ExtendKernel( SceneView sv, PathBuffers pb, const uint32_t* queue, const uint32_t* countPtr,
+                                                         uint32_t fixedCount, uint64_t* stats )
+{
+    const uint32_t count = countPtr ? *countPtr : fixedCount;
+    Counters cnt;
+    for ( uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < count; i += gridDim.x * kBlock )
+    {
+        const uint32_t p = queue ? queue[i] : i;
+        const float4 o = pb.rayO[p], d = pb.rayD[p];
+        HitRecord h = TraceClosest( sv, F3( o ), F3( d ), cnt );
+        cnt.rays++;
+        pb.hit[p] = make_float4( h.t, h.u, h.v, __int_as_float( h.prim ) );
+    }
+    FlushCounter( stats, ST_RAYS_CLOSEST, cnt.rays );
+    FlushCounter( stats, ST_NODES_CLOSEST, cnt.nodes );
+    FlushCounter( stats, ST_TRI_CLOSEST, cnt.tris );
+    FlushCounter( stats, ST_SPH_CLOSEST, cnt.spheres );
+}
+
+// Appends `value` to a queue for every lane with `flag` set: one atomic per wave.
+__device__ __forceinline__ void WaveAppend( bool flag, uint32_t value, uint32_t* queue, uint32_t* counter )
+{
+    const unsigned long long mask = __ballot( flag );
+    if ( mask == 0 ) return;
+    const int lane   = threadIdx.x & 63;
+    const int leader = __ffsll( static_cast< long long >( mask ) ) - 1;
+    uint32_t base = 0;
+    if ( lane == leader ) base = atomicAdd( counter, static_cast< uint32_t >( __popcll( mask ) ) );
+    base = __shfl( base, leader, 64 );
+    if ( flag ) queue[base + __popcll( mask & ( ( 1ull << lane ) - 1ull ) )] = value;
+}
+
+__global__ __launch_bounds__( kBlock ) void ShadeKernel( SceneView sv, RngParams rng, PathBuffers pb, int bounce, int maxDepth,
+                                                        uint32_t width, uint32_t height, uint32_t sampleBegin, const uint32_t* queue,
+                                                        const uint32_t* countPtr, uint32_t fixedCount, uint64_t* stats )
+{
+    const uint32_t count     = countPtr ? *countPtr : fixedCount;
+    const uint32_t numPixels = width * height;
+    const int cur = bounce & 1, nxt = cur ^ 1;
+    uint32_t* nextQueue   = pb.queue[nxt];
+    uint32_t* nextCount   = pb.counts + 2 * bounce;
+    uint32_t* shadowCount = pb.counts + 2 * bounce + 1;
+    uint32_t shaded = 0;
+
+    // every lane of a wave runs the same number of iterations so that the wave-wide appends stay convergent
+    const uint32_t stride = gridDim.x * kBlock;
+    const uint32_t rounds = ( count + stride - 1 ) / stride;
+    for ( uint32_t round = 0; round < rounds; ++round )
+    {
+        const uint32_t i  = round * stride + blockIdx.x * kBlock + threadIdx.x;
+        bool alive = false, anyShadow = false;
+        uint32_t p = 0;
+        if ( i < count )
+        {
+            p = queue ? queue[i] : i;
+            const f3 o = F3( pb.rayO[p] ), d = F3( pb.rayD[p] );
+            const f3 T = F3( pb.thr[cur][p] );
+            const float4 hr = pb.hit[p];
+            const int prim  = __float_as_int( hr.w );
+            f3 L = bounce == 0 ? F3( 0.0f, 0.0f, 0.0f ) : F3( pb.rad[p] );
+
+            if ( prim < 0 )
+            {
+                L = L + T * Environment( sv, d ); // path_tracer.cpp:116-120
+                pb.rad[p] = F4( L, 0.0f );
+            }
+            else
+            {
+                shaded++;
+                const float t = hr.x, u = hr.y, v = hr.z;
+                f3 position = o + d * t; // Ray::Evaluate
+                f3 normal, tangent, bitangent;
+                float tu, tv;
+                int material;
+                const float4 q0 = sv.prims[3 * prim];
+                if ( __float_as_uint( q0.w ) == kTagTriangle )
+                {
+                    // Triangle::Intersect attribute interpolation (src/shapes.cpp:123-130)
+                    const float4* a = sv.triShade + 7 * static_cast< size_t >( prim );
+                    const float4 a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3], a4 = a[4], a5 = a[5], a6 = a[6];
+                    const f3 n0 = F3( a0.x, a0.y, a0.z ), n1 = F3( a0.w, a1.x, a1.y ), n2 = F3( a1.z, a1.w, a2.x );
+                    const f3 t0 = F3( a2.y, a2.z, a2.w ), t1 = F3( a3.x, a3.y, a3.z ), t2 = F3( a3.w, a4.x, a4.y );
+                    const float w = 1 - u - v;
+                    normal    = Normalize( n0 * w + n1 * u + n2 * v );
+                    tangent   = Normalize( t0 * w + t1 * u + t2 * v );
+                    bitangent = Cross( normal, tangent );
+                    tu        = ( w * a4.z + u * a5.x ) + v * a5.z;
+                    tv        = ( w * a4.w + u * a5.y ) + v * a5.w;
+                    material  = __float_as_int( a6.x );
+                }
+                else
+                {
+                    // Sphere::Intersect (src/shapes.cpp:61-73).  atan2 / sin / cos are the double functions in
+                    // the reference's build, acosf the float one.
+                    const float4 q1 = sv.prims[3 * prim + 1];
+                    const float4* s = sv.spheres + 6 * __float_as_uint( q1.y );
+                    const float4 c0 = s[0], c1 = s[1], c2 = s[2], c3 = s[3];
+                    normal   = Normalize( position - F3( q0 ) );
+                    f3 lo    = MatMul( c0, c1, c2, c3, o, 1.0f );
+                    f3 ld    = MatMul( c0, c1, c2, c3, d, 0.0f );
+                    f3 lp    = lo + ld * t;
+                    float theta = static_cast< float >( atan2( static_cast< double >( lp.z ), static_cast< double >( lp.x ) ) );
+                    float phi   = static_cast< float >( acos( static_cast< double >( -lp.y ) ) );
+                    tu       = -0.5f * ( theta / kPi + 1 );
+                    tv       = phi / kPi;
+                    double ds, dc;
+                    sincos( static_cast< double >( theta ), &ds, &dc );
+                    tangent   = F3( static_cast< float >( -ds ), 0.0f, static_cast< float >( dc ) );
+                    bitangent = Cross( normal, tangent );
+                    material  = __float_as_int( s[5].x );
+                }
+                const f3 wo = -d;
+                position    = position + normal * kEpsilon; // path_tracer.cpp:122
+
+                const float4 m0 = sv.materials[2 * material], m1 = sv.materials[2 * material + 1];
+                if ( bounce == 0 && Dot( wo, normal ) > 0 ) L = L + T * F3( m1 ); // path_tracer.cpp:125-128
+                if ( bounce == 0 ) pb.rad[p] = F4( L, 0.0f );
+
+                f3 Kd = F3( m0 ); // Material::GetAlbedo (src/resource/material.cpp:34-43)
+                const int tex = __float_as_int( m0.w );
+                if ( tex >= 0 ) Kd = Kd * TextureFetch( sv, tex, tu, tv );
+                const f3 F = Kd / kPi; // BRDF::F (src/resource/material.cpp:15-18)
+
+                // LDirect / EstimateSingleDirect (path_tracer.cpp:74-104): one shadow record per light sample.
+                // The visibility test and the sum happen in ConnectKernel.
+                const uint32_t pixel = p % numPixels, sample = sampleBegin + p / numPixels;
+                const uint32_t drawBase = 2u + static_cast< uint32_t >( bounce ) * static_cast< uint32_t >( sv.drawsPerBounce );
+                int slot = 0;
+                for ( uint32_t li = 0; li < sv.numLights; ++li )
+                {
+                    const DevLight& l = sv.lights[li];
+                    for ( int smp = 0; smp < l.nSamples; ++smp, ++slot )
+                    {
+                        f3 wi, Li = F3( l.Lemit );
+                        float pdf = 1.0f, tMax;
+                        bool skip = false;
+                        if ( l.type == PT_LIGHT_POINT ) // src/lights.cpp:8-23
+                        {
+                            f3 toLight = F3( l.a ) - position;
+                            wi   = Normalize( toLight );
+                            tMax = Length( toLight );
+                            Li   = Li / ( tMax * tMax );
+                        }
+                        else if ( l.type == PT_LIGHT_DIRECTIONAL ) // src/lights.cpp:25-38
+                        {
+                            wi   = -F3( l.a );
+                            tMax = FLT_MAX;
+                        }
+                        else // src/lights.cpp:40-55 over src/shapes.cpp:11-30
+                        {
+                            // f( Rand(), Rand() ): g++ evaluates the arguments right to left, so the first
+                            // draw is u2 and the second u1
+                            float u2, u1;
+                            DrawPair( rng, pixel, sample, drawBase + 2u * ( l.drawOffset + smp ), &u2, &u1 );
+                            f3 sp, sn;
+                            if ( l.shapeType == PT_PRIM_TRIANGLE ) // src/shapes.cpp:104-115, src/sampling.cpp:63-67
+                            {
+                                float su0 = sqrtf( u1 );
+                                float bu = 1 - su0, bv = u2 * su0, bw = 1 - bu - bv;
+                                sp = F3( l.v0 ) * bu + F3( l.v1 ) * bv + F3( l.v2 ) * bw;
+                                sn = Normalize( F3( l.n0 ) * bu + F3( l.n1 ) * bv + F3( l.n2 ) * bw );
+                            }
+                            else // src/shapes.cpp:42-50
+                            {
+                                sn = UniformSampleSphere( u1, u2 );
+                                sp = F3( l.a ) + sn * l.radius;
+                            }
+                            pdf = l.invArea;
+                            f3 toLight = sp - position;
+                            if ( Length( toLight ) == 0 )
+                                pdf = 0;
+                            else
+                            {
+                                float r2 = Dot( toLight, toLight );
+                                f3 w     = Normalize( toLight );
+                                pdf *= r2 / AbsDot( sn, -w );
+                                if ( isinf( pdf ) ) pdf = 0.0f;
+                            }
+                            wi   = Normalize( sp - position );
+                            tMax = Length( sp - position );
+                            if ( static_cast< double >( tMax ) < 0.002 ) skip = true;
+                            if ( !( Dot( -wi, sn ) > 0 ) ) skip = true; // one-sided emitter
+                        }
+                        f3 est = F3( 0.0f, 0.0f, 0.0f );
+                        if ( pdf == 0 )
+                            skip = true;
+                        else
+                            est = ( ( F * Li ) * AbsDot( normal, wi ) ) / pdf; // path_tracer.cpp:87
+                        if ( IsZero( est ) ) skip = true;
+                        const size_t rec = static_cast< size_t >( slot ) * pb.capacity + p;
+                        pb.shDir[rec] = F4( wi, skip ? -1.0f : tMax );
+                        if ( !skip )
+                        {
+                            pb.shEst[rec] = F4( est, 0.0f );
+                            anyShadow     = true;
+                        }
+                    }
+                }
+
+                // BRDF::Sample_F / Pdf (src/resource/material.cpp:20-32) and the throughput update
+                // (path_tracer.cpp:139-152)
+                float u2, u1;
+                DrawPair( rng, pixel, sample, drawBase + static_cast< uint32_t >( sv.drawsPerBounce ) - 2u, &u2, &u1 );
+                f3 local = CosineSampleHemisphere( u1, u2 );
+                f3 wi    = tangent * local.x + bitangent * local.y + normal * local.z;
+                bool sameHemisphere = Dot( wo, normal ) * Dot( wi, normal ) > 0;
+                float pdf = sameHemisphere ? AbsDot( wi, normal ) / kPi : 0.0f;
+                if ( !( pdf == 0.0f || IsZero( F ) ) )
+                {
+                    f3 Tn = T * ( ( F * AbsDot( wi, normal ) ) / pdf );
+                    if ( !IsZero( Tn ) && bounce + 1 < maxDepth )
+                    {
+                        alive          = true;
+                        pb.rayD[p]     = F4( wi, 0.0f );
+                        pb.thr[nxt][p] = F4( Tn, 0.0f );
+                    }
+                }
+                if ( alive || anyShadow ) pb.rayO[p] = F4( position, 0.0f );
+            }
+        }
+        WaveAppend( alive, p, nextQueue, nextCount );
+        WaveAppend( anyShadow, p, pb.shadowQueue, shadowCount );
+    }
+    FlushCounter( stats, ST_SHADED, shaded );
+}
+
+// Visibility of the shadow records of one path, then L += throughput * sum over lights of
+// ( sum over samples ) / nSamples (path_tracer.cpp:90-104, 133-134), in light order.
+__global__ __launch_bounds__( kBlock ) void ConnectKernel( SceneView sv, PathBuffers pb, int bounce, uint64_t* stats )
+{
+    const uint32_t count = pb.counts[2 * bounce + 1];
+    const int cur = bounce & 1;
+    Counters cnt;
+    for ( uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < count; i += gridDim.x * kBlock )
+    {
+        const uint32_t p = pb.shadowQueue[i];
+        const f3 o = F3( pb.rayO[p] );
+        f3 Ldirect = F3( 0.0f, 0.0f, 0.0f );
+        int slot = 0;
+        for ( uint32_t li = 0; li < sv.numLights; ++li )
+        {
+            const int nSamples = sv.lights[li].nSamples;
+            f3 Ld = F3( 0.0f, 0.0f, 0.0f );
+            for ( int smp = 0; smp < nSamples; ++smp, ++slot )
+            {
+                const size_t rec = static_cast< size_t >( slot ) * pb.capacity + p;
+                const float4 dir = pb.shDir[rec];
+                if ( dir.w < 0.0f ) continue;
+                cnt.rays++;
+                if ( !TraceAny( sv, o, F3( dir ), dir.w, cnt ) ) Ld = Ld + F3( pb.shEst[rec] );
+            }
+            Ldirect = Ldirect + Ld / static_cast< float >( nSamples );
+        }
+        const f3 T = F3( pb.thr[cur][p] );
+        f3 L       = F3( pb.rad[p] );
+        pb.rad[p]  = F4( L + T * Ldirect, 0.0f );
+    }
+    FlushCounter( stats, ST_RAYS_SHADOW, cnt.rays );
+    FlushCounter( stats, ST_NODES_SHADOW, cnt.nodes );
+    FlushCounter( stats, ST_TRI_SHADOW, cnt.tris );
+    FlushCounter( stats, ST_SPH_SHADOW, cnt.spheres );
+}
+
+// totalColor += Li( sample ) in sample order (path_tracer.cpp:185-191); film.w counts the samples
+__global__ __launch_bounds__( kBlock ) void FilmKernel( PathBuffers pb, float4* film, uint32_t numPixels, uint32_t samplesInPass )
+{
+    for ( uint32_t pixel = blockIdx.x * kBlock + threadIdx.x; pixel < numPixels; pixel += gridDim.x * kBlock )
+    {
+        float4 f = film[pixel];
+        for ( uint32_t s = 0; s < samplesInPass; ++s )
+        {
+            const float4 L = pb.rad[static_cast< size_t >( s ) * numPixels + pixel];
+            f.x += L.x;
+            f.y += L.y;
+            f.z += L.z;
+        }
+        f.w += static_cast< float >( samplesInPass );
+        film[pixel] = f;
+    }
+}
+
+// Uncharted2TonemapHelper (src/tonemap.cpp:36-45)
+__device__ __forceinline__ float U2Helper( float x )
+{
+    const float A = 0.15f, B = 0.50f, C = 0.10f, D = 0.20f, E = 0.02f, F = 0.30f;
+    return ( ( x * ( A * x + C * B ) + D * E ) / ( x * ( A * x + B ) + D * F ) ) - E / F;
+}
+
+// mean = total / spp (path_tracer.cpp:193), then tonemap, gamma, clamp (path_tracer.cpp:211-219,
+// src/tonemap.cpp:6-9, 29-33, 47-53).  powf of the host's libm is correctly rounded for practically every
+// argument; pow in double rounded once gives the same float.
+__global__ __launch_bounds__( kBlock ) void TonemapKernel( const float4* film, float* linearOut, float* tonemappedOut, uint32_t numPixels,
+                                                          float exposure, float gamma, uint32_t op )
+{
+    const float whiteScale = 1.0f / U2Helper( 11.2f );
+    const float invGamma   = 1.0f / gamma;
+    for ( uint32_t pixel = blockIdx.x * kBlock + threadIdx.x; pixel < numPixels; pixel += gridDim.x * kBlock )
+    {
+        const float4 f = film[pixel];
+        float c[3] = { f.x / f.w, f.y / f.w, f.z / f.w };
+        if ( linearOut )
+        {
+            linearOut[3 * pixel + 0] = c[0];
+            linearOut[3 * pixel + 1] = c[1];
+            linearOut[3 * pixel + 2] = c[2];
+        }
+        if ( tonemappedOut )
+        {
+            for ( int k = 0; k < 3; ++k )
+            {
+                float x = c[k];
+                if ( op == PT_TONEMAP_UNCHARTED2 )
+                    x = U2Helper( exposure * x ) * whiteScale;
+                else if ( op == PT_TONEMAP_REINHARD )
+                {
+                    float a = exposure * x;
+                    x       = a / ( 1.0f + a );
+                }
+                if ( op != PT_TONEMAP_NONE )
+                {
+                    x = static_cast< float >( pow( static_cast< double >( x ), static_cast< double >( invGamma ) ) );
+                    x = x < 0.0f ? 0.0f : x;
+                    x = 1.0f < x ? 1.0f : x;
+                }
+                tonemappedOut[3 * pixel + k] = x;
+            }
+        }
+    }
+}
+
+// Batch queries behind pt_trace_closest / pt_trace_any: device arrays of n rays, one thread per ray.
+__global__ __launch_bounds__( kBlock ) void TraceClosestKernel( SceneView sv, uint64_t n, const float* origins, const float* dirs, int32_t* prim,
+                                                               float* t, float* u, float* v, uint32_t* nodes, uint32_t* tests )
+{
+    for ( uint64_t i = static_cast< uint64_t >( blockIdx.x ) * kBlock + threadIdx.x; i < n; i += static_cast< uint64_t >( gridDim.x ) * kBlock )
+    {
+        Counters cnt;
+        HitRecord h = TraceClosest( sv, F3( origins + 3 * i ), F3( dirs + 3 * i ), cnt );
+        if ( prim ) prim[i] = h.prim;
+        if ( t ) t[i] = h.t;
+        if ( u ) u[i] = h.u;
+        if ( v ) v[i] = h.v;
+        if ( nodes ) nodes[i] = cnt.nodes;
+        if ( tests ) tests[i] = cnt.tris + cnt.spheres;
+    }
+}
+
+__global__ __launch_bounds__( kBlock ) void TraceAnyKernel( SceneView sv, uint64_t n, const float* origins, const float* dirs, const float* tMax,
+                                                           uint8_t* occluded, uint32_t* nodes, uint32_t* tests )
+{
+    for ( uint64_t i = static_cast< uint64_t >( blockIdx.x ) * kBlock + threadIdx.x; i < n; i += static_cast< uint64_t >( gridDim.x ) * kBlock )
+    {
+        Counters cnt;
+        bool occ = TraceAny( sv, F3( origins + 3 * i ), F3( dirs + 3 * i ), tMax[i], cnt );
+        occluded[i] = occ ? 1 : 0;
+        if ( nodes ) nodes[i] = cnt.nodes;
+        if ( tests ) tests[i] = cnt.tris + cnt.spheres;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ launch wrappers
+
+static int GridFor( const LaunchCfg& cfg, uint64_t work )
+{
+    uint64_t blocks = ( work + kBlock - 1 ) / kBlock;
+    if ( blocks < 1 ) blocks = 1;
+    if ( blocks > static_cast< uint64_t >( cfg.blocks ) ) blocks = cfg.blocks;
+    return static_cast< int >( blocks );
+}
+
+void LaunchRaygen( const LaunchCfg& cfg, const CameraFrame& cam, const RngParams& rng, const PathBuffers& pb, uint32_t width,
+                   uint32_t height, uint32_t sampleBegin, uint32_t numPaths )
+{
+    hipLaunchKernelGGL( RaygenKernel, dim3( GridFor( cfg, numPaths ) ), dim3( kBlock ), 0, cfg.stream, cam, rng, pb, width, height, sampleBegin, numPaths );
+}
+
+void LaunchExtend( const LaunchCfg& cfg, const SceneView& sv, const PathBuffers& pb, const uint32_t* queue, const uint32_t* countPtr,
+                   uint32_t fixedCount, uint64_t* stats )
+{
+    const uint64_t work = countPtr ? pb.capacity : fixedCount;
+    hipLaunchKernelGGL( ExtendKernel, dim3( GridFor( cfg, work ) ), dim3( kBlock ), 0, cfg.stream, sv, pb, queue, countPtr, fixedCount, stats );
+}
+
+void LaunchShade( const LaunchCfg& cfg, const SceneView& sv, const RngParams& rng, const PathBuffers& pb, int bounce, int maxDepth,
+                  uint32_t width, uint32_t height, uint32_t sampleBegin, const uint32_t* queue, const uint32_t* countPtr,
+                  uint32_t fixedCount, uint64_t* stats )
+{
+    const uint64_t work = countPtr ? pb.capacity : fixedCount;
+    hipLaunchKernelGGL( ShadeKernel, dim3( GridFor( cfg, work ) ), dim3( kBlock ), 0, cfg.stream, sv, rng, pb, bounce, maxDepth, width, height,
+                        sampleBegin, queue, countPtr, fixedCount, stats );
+}
+
+void LaunchConnect( const LaunchCfg& cfg, const SceneView& sv, const PathBuffers& pb, int bounce, uint64_t* stats )
+{
+    hipLaunchKernelGGL( ConnectKernel, dim3( GridFor( cfg, pb.capacity ) ), dim3( kBlock ), 0, cfg.stream, sv, pb, bounce, stats );
+}
+
+void LaunchFilm( const LaunchCfg& cfg, const PathBuffers& pb, float4* film, uint32_t numPixels, uint32_t samplesInPass )
+{
+    hipLaunchKernelGGL( FilmKernel, dim3( GridFor( cfg, numPixels ) ), dim3( kBlock ), 0, cfg.stream, pb, film, numPixels, samplesInPass );
+}
+
+void LaunchTonemap( const LaunchCfg& cfg, const float4* film, float* linearOut, float* tonemappedOut, uint32_t numPixels, float exposure,
+                    float gamma, uint32_t op )
+{
+    hipLaunchKernelGGL( TonemapKernel, dim3( GridFor( cfg, numPixels ) ), dim3( kBlock ), 0, cfg.stream, film, linearOut, tonemappedOut, numPixels,
+                        exposure, gamma, op );
+}
+
+void LaunchTraceClosest( const LaunchCfg& cfg, const SceneView& sv, uint64_t n, const float* origins, const float* dirs, int32_t* prim,
+                         float* t, float* u, float* v, uint32_t* nodes, uint32_t* tests )
+{
+    hipLaunchKernelGGL( TraceClosestKernel, dim3( GridFor( cfg, n ) ), dim3( kBlock ), 0, cfg.stream, sv, n, origins, dirs, prim, t, u, v, nodes, tests );
+}
+
+void LaunchTraceAny( const LaunchCfg& cfg, const SceneView& sv, uint64_t n, const float* origins, const float* dirs, const float* tMax,
+                     uint8_t* occluded, uint32_t* nodes, uint32_t* tests )
+{
+    hipLaunchKernelGGL( TraceAnyKernel, dim3( GridFor( cfg, n ) ), dim3( kBlock ), 0, cfg.stream, sv, n, origins, dirs, tMax, occluded, nodes, tests );
+}
+
+} // namespace ptd

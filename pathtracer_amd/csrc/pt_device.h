@@ -1,0 +1,132 @@
+// Device-side data layout and launch interface of the path-tracing core (gfx950).
+//
+// All scene data is rewritten at upload into layouts chosen for 16-byte coalescable loads:
+//   nodes      2 x float4 per node (32 B): {lo.xyz, hi.x} {hi.y, hi.z, escape, leaf}
+//   prims      3 x float4 per primitive (48 B): triangle {v0, tag 0} {v1 - v0} {v2 - v0};
+//              sphere {centre, tag 1} {radius, sphere index}
+//   triShade   7 x float4 per triangle primitive (112 B): n0 n1 n2 t0 t1 t2 uv0 uv1 uv2 material
+//   spheres    6 x float4: world-to-local columns 0..3, {centre, radius}, {material}
+//   materials  2 x float4: {albedo, texture index} {Ke}
+//   lights     9 x float4, see DevLight
+// Path state lives in structure-of-float4 arrays indexed by path id (see PathBuffers).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ptd
+{
+
+constexpr uint32_t kInnerNode    = 0xFFFFFFFFu; // DevNode leaf word of an inner node
+constexpr uint32_t kLeafFirstMask = 0x0FFFFFFFu; // leaf word: low 28 bits first primitive, high 4 bits count - 1
+constexpr int kMaxLeafShapes     = 16;
+constexpr uint32_t kTagTriangle = 0, kTagSphere = 1;
+
+struct DevLight // 144 bytes
+{
+    uint32_t type;      // PT_LIGHT_*
+    int32_t nSamples;
+    uint32_t drawOffset; // area lights: index of this light's first sample among all area-light samples
+    uint32_t shapeType;  // area lights: PT_PRIM_TRIANGLE / PT_PRIM_SPHERE
+    float Lemit[3];
+    float invArea;       // area lights: 1 / Area(), the area pdf (src/shapes.cpp:48,113)
+    float a[3];          // point: position; directional: direction; sphere light: centre
+    float radius;        // sphere light
+    float v0[3], pad0;   // triangle light: vertices and vertex normals
+    float v1[3], pad1;
+    float v2[3], pad2;
+    float n0[3], pad3;
+    float n1[3], pad4;
+    float n2[3], pad5;
+};
+static_assert( sizeof( DevLight ) == 144, "DevLight is nine float4" );
+
+struct DevTexture
+{
+    int32_t width, height;
+    uint32_t offsetLo, offsetHi; // texel offset into the RGBA8 pool
+};
+
+struct SceneView
+{
+    const float4* nodes;
+    const float4* prims;
+    const float4* triShade;
+    const float4* spheres;
+    const float4* materials;
+    const DevTexture* textures;
+    const uint32_t* texels;
+    const DevLight* lights;
+    const float4* skybox; // 6 * w * h texels or nullptr
+    uint32_t numNodes;
+    uint32_t numLights;
+    int32_t shadowSlots;     // sum of nSamples over all lights
+    int32_t drawsPerBounce;  // 2 * (area light samples) + 2
+    int32_t skyboxWidth, skyboxHeight;
+    float background[3];
+};
+
+struct CameraFrame // src/path_tracer.cpp:168-173, computed on the host with the host's tanf
+{
+    float position[3];
+    float UL[3];
+    float dU[3];
+    float dV[3];
+};
+
+struct RngParams
+{
+    uint32_t mode;
+    uint32_t seedLo, seedHi;
+    const float* table;
+    uint64_t tableLen;
+    int32_t sppTotal;
+    int32_t tableDraws;
+};
+
+struct PathBuffers
+{
+    float4* rayO;      // origin.xyz
+    float4* rayD;      // direction.xyz
+    float4* thr[2];    // throughput, double buffered per bounce
+    float4* rad;       // accumulated radiance of the path
+    float4* hit;       // t, u, v, prim (int bits; -1 = miss)
+    float4* shDir;     // [slot * capacity + path]: wi.xyz, tMax (negative = no ray)
+    float4* shEst;     // [slot * capacity + path]: unoccluded contribution
+    uint32_t* queue[2];
+    uint32_t* shadowQueue;
+    uint32_t* counts;  // [bounce][2]: paths continuing into bounce + 1, paths with shadow rays
+    uint64_t capacity;
+};
+
+// Counter slots in the device statistics block
+enum
+{
+    ST_RAYS_CLOSEST, ST_RAYS_SHADOW, ST_NODES_CLOSEST, ST_NODES_SHADOW, ST_TRI_CLOSEST, ST_TRI_SHADOW,
+    ST_SPH_CLOSEST, ST_SPH_SHADOW, ST_SHADED, ST_COUNT
+};
+
+struct LaunchCfg
+{
+    hipStream_t stream;
+    int blocks; // grid size of the grid-stride kernels
+};
+
+// --- launch wrappers (kernels.hip) ---------------------------------------------------------------------
+void LaunchRaygen( const LaunchCfg& cfg, const CameraFrame& cam, const RngParams& rng, const PathBuffers& pb,
+                   uint32_t width, uint32_t height, uint32_t sampleBegin, uint32_t numPaths );
+void LaunchExtend( const LaunchCfg& cfg, const SceneView& sv, const PathBuffers& pb, const uint32_t* queue,
+                   const uint32_t* countPtr, uint32_t fixedCount, uint64_t* stats );
+void LaunchShade( const LaunchCfg& cfg, const SceneView& sv, const RngParams& rng, const PathBuffers& pb, int bounce,
+                  int maxDepth, uint32_t width, uint32_t height, uint32_t sampleBegin, const uint32_t* queue,
+                  const uint32_t* countPtr, uint32_t fixedCount, uint64_t* stats );
+void LaunchConnect( const LaunchCfg& cfg, const SceneView& sv, const PathBuffers& pb, int bounce, uint64_t* stats );
+void LaunchFilm( const LaunchCfg& cfg, const PathBuffers& pb, float4* film, uint32_t numPixels, uint32_t samplesInPass );
+void LaunchTonemap( const LaunchCfg& cfg, const float4* film, float* linearOut, float* tonemappedOut, uint32_t numPixels,
+                    float exposure, float gamma, uint32_t op );
+void LaunchTraceClosest( const LaunchCfg& cfg, const SceneView& sv, uint64_t n, const float* origins, const float* dirs,
+                         int32_t* prim, float* t, float* u, float* v, uint32_t* nodes, uint32_t* tests );
+void LaunchTraceAny( const LaunchCfg& cfg, const SceneView& sv, uint64_t n, const float* origins, const float* dirs,
+                     const float* tMax, uint8_t* occluded, uint32_t* nodes, uint32_t* tests );
+
+} // namespace ptd

@@ -1,0 +1,192 @@
+"""GPU parity: the HIP path, called through its C-ABI, against the CPU checker (oracle/) and the golden vectors
+the reference produced (tests/golden).
+
+Bars: hit primitive, t, u, v, occlusion bits and traversal counters are bit-exact.  Radiance in the
+deterministic modes (Philox or a replayed sample table): per pixel |gpu - cpu| <= 1e-4 * max(1, |cpu|), where the
+only arithmetic that is not bit-identical between the two is sin / cos / pow / atan2 / acos (device math library
+versus the host libm, both within an ulp); the tests also report how many pixels are exactly equal.
+"""
+import numpy as np
+import pytest
+
+from conftest import assert_bits_equal
+from oracle import checker
+from pathtracer_amd import abi, api
+
+pytestmark = pytest.mark.gpu
+
+RADIANCE_TOL = 1e-4
+
+
+def radiance_close(gpu, cpu, what):
+    err = np.abs(gpu - cpu) / np.maximum(1.0, np.abs(cpu))
+    exact = (gpu == cpu).all(axis=-1).mean()
+    print(f"{what}: max err {err.max():.3e}, exactly equal pixels {100 * exact:.2f} %")
+    assert np.isfinite(gpu).all(), f"{what}: non-finite radiance"
+    assert err.max() <= RADIANCE_TOL, f"{what}: max relative error {err.max():.3e} at {np.unravel_index(err.argmax(), err.shape)}"
+    return exact
+
+
+@pytest.fixture(scope="module")
+def device_scenes(scenes):
+    out = {}
+    for name, s in scenes.items():
+        small = s.with_image(48, 48)
+        desc = small.to_desc()
+        out[name] = (small, api.DeviceScene(desc), checker.OracleScene(desc))
+    yield out
+    for _, dev, _ in out.values():
+        dev.close()
+
+
+@pytest.mark.parametrize("name", ["cornell", "mixed"])
+def test_closest_hit_matches_reference_vectors(name, device_scenes, golden):
+    _, dev, _ = device_scenes[name]
+    g = golden[name]
+    got = dev.trace_closest(g["ray_o"], g["ray_d"])
+    assert np.array_equal(got["prim"], g["hit_prim"])
+    hit = g["hit_prim"] >= 0
+    assert_bits_equal(got["t"], g["hit_t"], "t")
+    assert_bits_equal(got["u"][hit], g["hit_u"][hit], "u")
+    assert_bits_equal(got["v"][hit], g["hit_v"][hit], "v")
+    assert np.array_equal(got["nodes"], g["hit_nodes"])
+    assert np.array_equal(got["prim_tests"], g["hit_prim_tests"])
+
+
+@pytest.mark.parametrize("name", ["cornell", "mixed"])
+def test_any_hit_matches_reference_vectors(name, device_scenes, golden):
+    _, dev, orc = device_scenes[name]
+    g = golden[name]
+    got = dev.trace_any(g["ray_o"], g["ray_d"], g["shadow_tmax"])
+    assert np.array_equal(got["occluded"], g["shadow_occluded"])
+    want = orc.occluded(g["ray_o"], g["ray_d"], g["shadow_tmax"])
+    assert np.array_equal(got["nodes"], want["nodes"])
+    assert np.array_equal(got["prim_tests"], want["prim_tests"])
+
+
+@pytest.mark.parametrize("name", ["cornell", "mixed"])
+def test_closest_hit_matches_oracle_on_large_batch(name, device_scenes):
+    scene, dev, orc = device_scenes[name]
+    rng = np.random.default_rng(5)
+    n = 300_000
+    lo, hi = scene.nodes["aabb_min"][0], scene.nodes["aabb_max"][0]
+    o = rng.uniform(lo - 0.5, hi + 0.5, (n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d[: n // 10, rng.integers(0, 3)] = 0.0
+    got, want = dev.trace_closest(o, d), orc.intersect(o, d)
+    assert np.array_equal(got["prim"], want["prim"])
+    assert_bits_equal(got["t"], want["t"], "t")
+    assert_bits_equal(got["u"], want["u"], "u")
+    assert_bits_equal(got["v"], want["v"], "v")
+    assert np.array_equal(got["nodes"], want["nodes"])
+    assert np.array_equal(got["prim_tests"], want["prim_tests"])
+    tmax = rng.uniform(0, 3, n).astype(np.float32)
+    got, want = dev.trace_any(o, d, tmax), orc.occluded(o, d, tmax)
+    assert np.array_equal(got["occluded"], want["occluded"])
+
+
+@pytest.mark.parametrize("name", ["cornell", "mixed"])
+@pytest.mark.parametrize("spp", [1, 8])
+def test_radiance_matches_reference_vectors(name, spp, device_scenes, golden):
+    _, dev, _ = device_scenes[name]
+    g = golden[name]
+    dev.render(spp, seed=7)
+    lin, _, stats = dev.readback()
+    want = g[f"li_sum_spp{spp}"] / np.float32(spp)
+    radiance_close(lin, want, f"{name} {spp} spp vs reference")
+    assert stats.samples == 48 * 48 * spp
+    assert stats.rays_closest == int(g[f"rays_spp{spp}"][0])
+    # the reference also traces shadow rays whose contribution is zero; the GPU path skips those
+    assert stats.rays_shadow <= int(g[f"rays_spp{spp}"][1])
+
+
+@pytest.mark.parametrize("name", ["cornell", "mixed"])
+def test_radiance_sample_table_mode(name, device_scenes, golden):
+    scene, dev, _ = device_scenes[name]
+    g = golden[name]
+    dev.render(2, table=g["table"], table_draws_per_sample=scene.draws_per_sample())
+    lin, _, _ = dev.readback()
+    radiance_close(lin, g["li_sum_table_spp2"] / np.float32(2), f"{name} table mode vs reference")
+
+
+@pytest.mark.parametrize("name", ["cornell", "mixed"])
+def test_radiance_and_counters_match_oracle(name, device_scenes):
+    _, dev, orc = device_scenes[name]
+    dev.render(16, seed=123)
+    lin, _, stats = dev.readback()
+    want, ostats = orc.li_image(16, seed=123)
+    exact = radiance_close(lin, want / np.float32(16), f"{name} 16 spp vs oracle")
+    assert exact > 0.98
+    assert stats.rays_closest == ostats["rays_closest"]
+    assert stats.nodes_closest == ostats["nodes_closest"]
+    assert stats.tri_tests_closest == ostats["tri_tests_closest"]
+    assert stats.sphere_tests_closest == ostats["sphere_tests_closest"]
+    assert stats.shaded_hits == ostats["shaded_hits"]
+
+
+def test_split_ranges_and_passes_are_bit_identical(device_scenes):
+    """Sample order is preserved across pt_render calls and across passes, so any split gives the same film."""
+    _, dev, _ = device_scenes["cornell"]
+    dev.render(8, seed=3)
+    whole, _, _ = dev.readback()
+    dev.render(8, 0, 3, seed=3)
+    dev.render(8, 3, 8, seed=3, accumulate=True)
+    split, _, _ = dev.readback()
+    assert_bits_equal(whole, split, "split ranges")
+    dev.render(8, seed=3, samples_per_pass=1)
+    passes, _, _ = dev.readback()
+    assert_bits_equal(whole, passes, "one sample per pass")
+    dev.render(8, seed=3)
+    again, _, _ = dev.readback()
+    assert_bits_equal(whole, again, "repeat")
+
+
+def test_tonemap_matches_reference_vectors(device_scenes, golden):
+    """Film -> Uncharted2 / Reinhard -> gamma -> clamp against the oracle's tonemap of the same linear image."""
+    scene, dev, _ = device_scenes["cornell"]
+    dev.render(4, seed=1)
+    lin, tm, _ = dev.readback(abi.PT_TONEMAP_UNCHARTED2)
+    want = checker.tonemap(lin, float(scene.camera["exposure"]), float(scene.camera["gamma"]), abi.PT_TONEMAP_UNCHARTED2)
+    assert np.abs(tm - want).max() <= 1e-6
+    _, tm, _ = dev.readback(abi.PT_TONEMAP_REINHARD)
+    want = checker.tonemap(lin, float(scene.camera["exposure"]), float(scene.camera["gamma"]), abi.PT_TONEMAP_REINHARD)
+    assert np.abs(tm - want).max() <= 1e-6
+    _, tm, _ = dev.readback(abi.PT_TONEMAP_NONE)
+    assert_bits_equal(tm, lin, "no tonemap")
+
+
+def test_depth_limits_and_empty_inputs(scenes):
+    base = scenes["cornell"].with_image(16, 16)
+    for depth in (0, 1, 2):
+        s = base.copy()
+        s.max_depth = depth
+        desc = s.to_desc()
+        with api.DeviceScene(desc) as dev:
+            orc = checker.OracleScene(desc)
+            dev.render(4, seed=9)
+            lin, _, _ = dev.readback()
+            want, _ = orc.li_image(4, seed=9)
+            radiance_close(lin, want / np.float32(4), f"depth {depth}")
+            empty = dev.trace_closest(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32))
+            assert len(empty["prim"]) == 0
+            dev.render(4, 2, 2, seed=9)  # empty sample range: film cleared, nothing rendered
+            assert dev.stats().samples == 0
+
+
+def test_invalid_scenes_are_rejected(scenes):
+    s = scenes["cornell"].copy()
+    s.nodes = s.nodes.copy()
+    s.nodes["offset"][0] = 10_000  # second child far outside the array
+    with pytest.raises(api.PtError) as e:
+        api.DeviceScene(s.to_desc())
+    assert e.value.code == abi.PT_ERR_INVALID_SCENE
+    s = scenes["cornell"].copy()
+    s.triangles = s.triangles.copy()
+    s.triangles["i0"][0] = 1_000_000
+    with pytest.raises(api.PtError):
+        api.DeviceScene(s.to_desc())
+    d = scenes["cornell"].to_desc()
+    d.version = 99
+    with pytest.raises(api.PtError) as e:
+        api.DeviceScene(d)
+    assert e.value.code == abi.PT_ERR_INVALID_ARG
