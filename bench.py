@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mrays/s and Msamples/s of the path-tracing hot path on N MI355X of one node.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on): the Sponza scene of
+resources/scenes/sponza.json at 1920x1080, depth 5.  sponza.obj and eight of its textures are not part of the
+reference checkout, so the scene is the procedural atrium stand-in of pathtracer_amd/host/generators.cpp with
+the same triangle count (262,267), camera, light and 24 textured 1024^2 materials; `data` says so.
+
+One step = one pass of the hot path over one batch: --spp-per-step samples of every pixel (default 16), i.e.
+1920 * 1080 * 16 = 33.2 M pixel samples per GPU and step.  Every rank renders its own sample indices of the
+same frame (weak scaling: per-GPU work per step is fixed); after the last step the per-GPU films are summed
+onto rank 0 with one RCCL reduce, inside the timed region.  --steps 64 on one GPU is the full 1024 spp frame.
+
+The JSON line carries `roofline` for the dominant kernel (closest-hit traversal or shadow-ray traversal,
+whichever took longer): algorithmic bytes from the kernel's own counters (32 B per node fetched, 48 B per
+triangle test, 84 / 16 B per sphere test, 48 / 36 B per ray in + out) over the kernel time measured with HIP
+events on the stream the kernels run on; and `cpu_baseline`: the CPU restatement of the same path
+(oracle/pt_oracle.c, OpenMP) timed on this host over a bounded sample of the same frame.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=16)
+    p.add_argument("--warmup", type=int, default=2)
+    p.add_argument("--spp-per-step", type=int, default=16)
+    p.add_argument("--width", type=int, default=1920)
+    p.add_argument("--height", type=int, default=1080)
+    p.add_argument("--triangles", type=int, default=262267)
+    p.add_argument("--texture-size", type=int, default=1024)
+    p.add_argument("--seed", type=int, default=0)
+    p.add_argument("--cpu-baseline-spp", type=int, default=32, help="samples per pixel the CPU baseline renders (0 = skip)")
+    p.add_argument("--save-image", default="", help="write the tonemapped frame of rank 0 to this file")
+    return p.parse_args()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        sys.exit(2)
+
+    import torch
+    from pathtracer_amd import abi, api, host, path_tracer
+
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (there is no CPU fallback for the hot path)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(local_rank)
+
+    # ---- scene (host side, outside the timed region) and upload
+    t0 = time.time()
+    hs = host.HostScene.atrium(seed=1, triangles=args.triangles, texture_size=args.texture_size)
+    hs.set_image(args.width, args.height, args.width / args.height)
+    desc = hs.desc(local_rank)
+    dev = api.DeviceScene(desc)
+    setup_s = time.time() - t0
+
+    spp_step = args.spp_per_step
+    spp_total = spp_step * world * (args.steps + args.warmup)
+
+    def run_step(step, profile):
+        first = (step * world + rank) * spp_step
+        dev.render(spp_total, first, first + spp_step, seed=args.seed, accumulate=True, profile=profile)
+
+    dev.clear_film()
+    for w in range(args.warmup):
+        run_step(w, False)
+    warm = dev.stats()
+
+    barrier()
+    t_start = time.perf_counter()
+    for k in range(args.steps):
+        run_step(args.warmup + k, True)
+    if dist is not None:
+        path_tracer.reduce_film(dev, local_rank, dist)
+    barrier()
+    elapsed = time.perf_counter() - t_start
+
+    if dist is not None:
+        t = torch.tensor([elapsed], device=f"cuda:{local_rank}", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    stats = dev.stats()
+    counters = ["samples", "rays_closest", "rays_shadow", "nodes_closest", "nodes_shadow", "tri_tests_closest",
+                "tri_tests_shadow", "sphere_tests_closest", "sphere_tests_shadow", "shaded_hits"]
+    mine = {c: getattr(stats, c) - getattr(warm, c) for c in counters}   # timed steps only
+    if dist is not None:
+        t = torch.tensor([mine[c] for c in counters], device=f"cuda:{local_rank}", dtype=torch.int64)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        total = dict(zip(counters, [int(x) for x in t.tolist()]))
+    else:
+        total = mine
+
+    if rank == 0:
+        rays = total["rays_closest"] + total["rays_shadow"]
+        # dominant traversal kernel on this rank, timed with HIP events around every launch (PT_RENDER_PROFILE)
+        ms = {abi.KERNEL_NAMES[i]: stats.kernel_ms[i] for i in range(abi.PT_K_COUNT)}
+        launches = {abi.KERNEL_NAMES[i]: int(stats.launches[i] - warm.launches[i]) for i in range(abi.PT_K_COUNT)}
+        bytes_closest = 32 * mine["nodes_closest"] + 48 * mine["tri_tests_closest"] + 84 * mine["sphere_tests_closest"] + 48 * mine["rays_closest"]
+        bytes_shadow = 32 * mine["nodes_shadow"] + 48 * mine["tri_tests_shadow"] + 16 * mine["sphere_tests_shadow"] + 36 * mine["rays_shadow"]
+        if ms["extend"] >= ms["connect"]:
+            kernel, kbytes, kms, klaunch, krays = "ExtendKernel", bytes_closest, ms["extend"], launches["extend"], mine["rays_closest"]
+        else:
+            kernel, kbytes, kms, klaunch, krays = "ConnectKernel", bytes_shadow, ms["connect"], launches["connect"], mine["rays_shadow"]
+        achieved = kbytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+        roofline = {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "bytes_per_launch": round(kbytes / max(1, klaunch)), "avg_launch_ms": round(kms / max(1, klaunch), 4),
+                    "launches": klaunch, "bytes_per_ray": round(kbytes / max(1, krays), 1),
+                    "grays_per_s_in_kernel": round(krays / (kms * 1e-3) / 1e9, 3) if kms > 0 else 0.0}
+
+        cpu = None
+        if args.cpu_baseline_spp > 0 and world == 1:
+            from oracle import checker
+            orc = checker.OracleScene(desc)
+            t1 = time.perf_counter()
+            _, ostats = orc.li_image(spp_total, 0, args.cpu_baseline_spp, seed=args.seed)
+            cpu_s = time.perf_counter() - t1
+            cpu_rays = ostats["rays_closest"] + ostats["rays_shadow"]
+            cpu = {"value": round(cpu_rays / cpu_s / 1e6, 3), "unit": "Mrays/s", "cores": checker.max_threads(), "kind": "port",
+                   "msamples_per_s": round(ostats["samples"] / cpu_s / 1e6, 4), "seconds": round(cpu_s, 2),
+                   "sample": f"samples 0..{args.cpu_baseline_spp - 1} of every pixel of the same {args.width}x{args.height} frame "
+                             f"({ostats['samples']} pixel samples, {cpu_rays} rays incl. zero-contribution shadow rays), "
+                             f"oracle/pt_oracle.c with OpenMP"}
+
+        if args.save_image:
+            _, tm, _ = dev.readback(abi.PT_TONEMAP_UNCHARTED2, linear=False)
+            host.write_image(args.save_image, tm)
+
+        out = {
+            "metric": "Mrays/s (closest-hit + shadow rays traced, whole job), sponza-class scene 1080p depth 5",
+            "value": round(rays / elapsed / 1e6, 2),
+            "unit": "Mrays/s",
+            "msamples_per_s": round(total["samples"] / elapsed / 1e6, 3),
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed * 1e3 / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"sponza.json stand-in (procedural atrium, {args.triangles} triangles, 24 textured materials "
+                                   f"{args.texture_size}^2, camera/light of resources/scenes/sponza.json) {args.width}x{args.height}, "
+                                   f"depth 5, {spp_step} spp per step and GPU",
+                       "spp_rendered": spp_step * world * args.steps, "sample_split": f"{world} x {spp_step} spp per step",
+                       "rays_per_sample": round(rays / max(1, total["samples"]), 3),
+                       "nodes_per_ray": round((total["nodes_closest"] + total["nodes_shadow"]) / max(1, rays), 2),
+                       "tri_tests_per_ray": round((total["tri_tests_closest"] + total["tri_tests_shadow"]) / max(1, rays), 3)},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "kernel_ms": {k: round(v, 3) for k, v in ms.items()},
+            "setup_s": round(setup_s, 2),
+        }
+        print(json.dumps(out), flush=True)
+
+    dev.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

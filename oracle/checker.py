@@ -54,6 +54,10 @@ def _p(a):
     return C.c_void_p(a.ctypes.data) if a is not None else None
 
 
+def max_threads():
+    return int(lib().pto_max_threads())
+
+
 def ray_aabb(o, inv_dir, bmin, bmax, max_t):
     o, inv_dir, bmin, bmax, max_t = map(_f32, (o, inv_dir, bmin, bmax, max_t))
     hit = np.zeros(len(max_t), np.uint8)

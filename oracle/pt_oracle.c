@@ -726,6 +726,15 @@ int pto_li_image( const PtoScene* s, int32_t spp_total, int32_t s0, int32_t s1, 
     return 0;
 }
 
+int pto_max_threads( void )
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
 /* Uncharted2TonemapHelper, src/tonemap.cpp:36-45 */
 static float u2_helper( float x )
 {

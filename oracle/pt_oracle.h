@@ -59,6 +59,9 @@ int pto_li_image( const PtoScene* scene, int32_t spp_total, int32_t s0, int32_t 
                   const float* table, uint64_t table_len, int32_t draws_per_sample, int32_t threads, float* rgb_sum,
                   PtoStats* stats );
 
+/* Number of OpenMP threads pto_li_image uses when `threads` is 0. */
+int pto_max_threads( void );
+
 /* Tonemap (op = PT_TONEMAP_*), gamma, clamp of src/path_tracer.cpp:211-219 on n RGB triples. */
 int pto_tonemap( uint64_t n, const float* rgb, float exposure, float gamma, uint32_t op, float* out );
 

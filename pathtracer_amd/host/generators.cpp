@@ -167,15 +167,22 @@ namespace
         for ( uint32_t idx : part.indices ) mesh.indices.push_back( base + idx );
     }
 
-    Surface Plane( vec3 origin, vec3 eu, vec3 ev )
+    // Rectangle origin + u * eu + v * ev whose face normal (counter-clockwise winding) points along `facing`;
+    // the u axis is reversed if the given axes would face the other way.
+    Surface Plane( vec3 origin, vec3 eu, vec3 ev, vec3 facing )
     {
+        if ( dot( cross( eu, ev ), facing ) < 0 )
+        {
+            origin = origin + eu;
+            eu     = -eu;
+        }
         return [=]( float u, float v ) { return origin + eu * u + ev * v; };
     }
 
     Surface Cylinder( vec3 base, float radius, float height, float bulge )
     {
         return [=]( float u, float v ) {
-            float a = u * 6.2831853f;
+            float a = -u * 6.2831853f; // clockwise seen from above: the face normals point outwards
             float r = radius * ( 1.0f + bulge * std::sin( v * 3.1415927f ) );
             return base + vec3( r * std::cos( a ), height * v, r * std::sin( a ) );
         };
@@ -203,7 +210,7 @@ namespace
     Surface Lathe( vec3 base, float height, std::function< float( float ) > radius )
     {
         return [=]( float u, float v ) {
-            float a = u * 6.2831853f, r = radius( v );
+            float a = -u * 6.2831853f, r = radius( v ); // outward normals, as for Cylinder
             return base + vec3( r * std::cos( a ), height * v, r * std::sin( a ) );
         };
     }
@@ -284,18 +291,18 @@ void GenerateAtrium( HostScene& scene, uint32_t seed, int targetTriangles, int t
     };
     const float X = 1800, Z = 1000, courtZ = 400, H1 = 450, H2 = 950, HR = 1000;
 
-    add( Plane( { -X, 0, Z }, { 2 * X, 0, 0 }, { 0, 0, -2 * Z } ), 72, 40, false, FLOOR, 18, 10 );                       // ground floor
+    add( Plane( { -X, 0, Z }, { 2 * X, 0, 0 }, { 0, 0, -2 * Z }, { 0, 1, 0 } ), 72, 40, false, FLOOR, 18, 10 );                       // ground floor
     for ( int side = -1; side <= 1; side += 2 )
     {
         float z0 = side * courtZ, z1 = side * Z;
-        add( Plane( { -X, H1, z0 }, { 2 * X, 0, 0 }, { 0, 0, z1 - z0 } ), 72, 12, false, CEILING, 18, 3 );              // gallery floor (top)
-        add( Plane( { -X, H1 - 40, z1 }, { 2 * X, 0, 0 }, { 0, 0, z0 - z1 } ), 72, 12, false, CEILING, 18, 3 );         // gallery floor (underside)
-        add( Plane( { -X, H1 - 40, z0 }, { 2 * X, 0, 0 }, { 0, 40, 0 } ), 72, 2, false, DETAILS, 18, 1 );               // slab edge
-        add( Plane( { -X, H2, z1 }, { 2 * X, 0, 0 }, { 0, 0, z0 - z1 } ), 72, 12, false, ROOF, 18, 3 );                 // aisle roof underside
-        add( Plane( { -X, HR, z0 }, { 2 * X, 0, 0 }, { 0, 0, z1 - z0 } ), 36, 6, false, ROOF, 18, 3 );                  // aisle roof top
-        add( Plane( { -X, H2, z0 }, { 2 * X, 0, 0 }, { 0, HR - H2, 0 } ), 72, 2, false, DETAILS, 18, 1 );               // roof edge
-        add( Plane( { side * X, 0, -side * Z }, { 0, 0, side * 2 * Z }, { 0, HR, 0 } ), 40, 24, false, BACKGROUND, 10, 5 ); // end wall (x = +-X)
-        add( Plane( { side > 0 ? -X : X, 0, z1 }, { side > 0 ? 2 * X : -2 * X, 0, 0 }, { 0, HR, 0 } ), 72, 24, false, BRICKS, 18, 5 ); // long wall
+        add( Plane( { -X, H1, z0 }, { 2 * X, 0, 0 }, { 0, 0, z1 - z0 }, { 0, 1, 0 } ), 72, 12, false, CEILING, 18, 3 );              // gallery floor (top)
+        add( Plane( { -X, H1 - 40, z1 }, { 2 * X, 0, 0 }, { 0, 0, z0 - z1 }, { 0, -1, 0 } ), 72, 12, false, CEILING, 18, 3 );         // gallery floor (underside)
+        add( Plane( { -X, H1 - 40, z0 }, { 2 * X, 0, 0 }, { 0, 40, 0 }, { 0, 0, -1.0f * side } ), 72, 2, false, DETAILS, 18, 1 );               // slab edge
+        add( Plane( { -X, H2, z1 }, { 2 * X, 0, 0 }, { 0, 0, z0 - z1 }, { 0, -1, 0 } ), 72, 12, false, ROOF, 18, 3 );                 // aisle roof underside
+        add( Plane( { -X, HR, z0 }, { 2 * X, 0, 0 }, { 0, 0, z1 - z0 }, { 0, 1, 0 } ), 36, 6, false, ROOF, 18, 3 );                  // aisle roof top
+        add( Plane( { -X, H2, z0 }, { 2 * X, 0, 0 }, { 0, HR - H2, 0 }, { 0, 0, -1.0f * side } ), 72, 2, false, DETAILS, 18, 1 );               // roof edge
+        add( Plane( { side * X, 0, -side * Z }, { 0, 0, side * 2 * Z }, { 0, HR, 0 }, { -1.0f * side, 0, 0 } ), 40, 24, false, BACKGROUND, 10, 5 ); // end wall (x = +-X)
+        add( Plane( { -X, 0, z1 }, { 2 * X, 0, 0 }, { 0, HR, 0 }, { 0, 0, -1.0f * side } ), 72, 24, false, BRICKS, 18, 5 ); // long wall
         for ( int i = 0; i <= 10; ++i )
         {
             float x = -1500.0f + 300.0f * i;
@@ -318,11 +325,11 @@ void GenerateAtrium( HostScene& scene, uint32_t seed, int targetTriangles, int t
     for ( int end = -1; end <= 1; end += 2 ) // end galleries close the roof ring; the courtyard stays open to the sky
     {
         float x0 = end * 1200.0f, x1 = end * X;
-        add( Plane( { x0, H2, -courtZ }, { x1 - x0, 0, 0 }, { 0, 0, 2 * courtZ } ), 12, 16, false, ROOF, 3, 4 );
-        add( Plane( { x0, HR, courtZ }, { x1 - x0, 0, 0 }, { 0, 0, -2 * courtZ } ), 8, 8, false, ROOF, 3, 4 );
-        add( Plane( { x0, H2, end > 0 ? courtZ : -courtZ }, { 0, 0, end > 0 ? -2 * courtZ : 2 * courtZ }, { 0, HR - H2, 0 } ), 16, 2, false, DETAILS, 4, 1 );
-        add( Plane( { x0, H1, -courtZ }, { x1 - x0, 0, 0 }, { 0, 0, 2 * courtZ } ), 12, 16, false, CEILING, 3, 4 );
-        add( Plane( { x0, H1 - 40, courtZ }, { x1 - x0, 0, 0 }, { 0, 0, -2 * courtZ } ), 12, 16, false, CEILING, 3, 4 );
+        add( Plane( { x0, H2, -courtZ }, { x1 - x0, 0, 0 }, { 0, 0, 2 * courtZ }, { 0, -1, 0 } ), 12, 16, false, ROOF, 3, 4 );
+        add( Plane( { x0, HR, courtZ }, { x1 - x0, 0, 0 }, { 0, 0, -2 * courtZ }, { 0, 1, 0 } ), 8, 8, false, ROOF, 3, 4 );
+        add( Plane( { x0, H2, -courtZ }, { 0, 0, 2 * courtZ }, { 0, HR - H2, 0 }, { -1.0f * end, 0, 0 } ), 16, 2, false, DETAILS, 4, 1 );
+        add( Plane( { x0, H1, -courtZ }, { x1 - x0, 0, 0 }, { 0, 0, 2 * courtZ }, { 0, 1, 0 } ), 12, 16, false, CEILING, 3, 4 );
+        add( Plane( { x0, H1 - 40, courtZ }, { x1 - x0, 0, 0 }, { 0, 0, -2 * courtZ }, { 0, -1, 0 } ), 12, 16, false, CEILING, 3, 4 );
         // lion-head stand-in: bumpy sphere on the end wall
         vec3 c( end * ( X - 60.0f ), 260, 0 );
         uint32_t ns = Hash( seed + 77u * ( end + 2 ) );
@@ -445,7 +452,7 @@ void GenerateKnot( HostScene& scene, uint32_t seed, int targetTriangles )
         vec3 tangent = normalize( ahead - c );
         vec3 n1 = normalize( cross( tangent, vec3( 0.13f, 0.31f, 0.94f ) ) );
         vec3 n2 = cross( tangent, n1 );
-        float b = v * 6.2831853f;
+        float b = -v * 6.2831853f; // this sense of rotation makes the tube's face normals point outwards
         float r = 0.11f * ( 1.0f + 0.35f * Fbm( u * 96, v * 6, ns ) );
         return c + n1 * ( r * std::cos( b ) ) + n2 * ( r * std::sin( b ) );
     };
