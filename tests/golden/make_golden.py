@@ -130,10 +130,12 @@ def golden_leaf():
     d = rng.normal(size=(n, 3)).astype(np.float32)
     d[:512, 0] = 0.0
     d[256:768, 1] = -0.0
-    with np.errstate(divide="ignore"):
-        inv = (np.float32(1.0) / d).astype(np.float32)
     bmin = rng.uniform(-1.5, 0.5, (n, 3)).astype(np.float32)
     bmax = (bmin + rng.uniform(0, 1.5, (n, 3))).astype(np.float32)
+    aimed = slice(768, 3072)                           # rays aimed at a point of their box: mostly hits
+    d[aimed] = (bmin[aimed] + (bmax - bmin)[aimed] * rng.uniform(0, 1, (2304, 3)) - o[aimed]).astype(np.float32)
+    with np.errstate(divide="ignore"):
+        inv = (np.float32(1.0) / d).astype(np.float32)
     bmax[1024:1536, 2] = bmin[1024:1536, 2]            # flat boxes
     o[:128, 0] = bmin[:128, 0]                         # origin on a slab plane with zero direction: NaN
     maxt = np.where(rng.uniform(size=n) < 0.3, np.float32(3.4028235e38), rng.uniform(0, 5, n)).astype(np.float32)

@@ -1,0 +1,160 @@
+"""Host library (libpthost.so): scene files, BVH build against the reference's node arrays, procedural scenes,
+image output.  CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+from pathtracer_amd import abi, host
+from test_oracle_vs_reference import shape_boxes
+
+
+@pytest.mark.parametrize("name", ["cornell", "mixed"])
+@pytest.mark.parametrize("method,tag", [(abi.PTH_SPLIT_SAH, "sah"), (abi.PTH_SPLIT_MIDDLE, "middle"), (abi.PTH_SPLIT_EQUAL_COUNTS, "equal")])
+def test_bvh_builder_matches_golden_reference_build(name, method, tag, scenes, golden):
+    """tests/golden/golden_bvh.npz holds what the reference's BVH::Build produced for these shape lists."""
+    s = scenes[name]
+    nodes, order = host.build_bvh(shape_boxes(s), method)
+    want = golden["bvh"][f"{name}_{tag}_nodes"]
+    assert np.array_equal(order, golden["bvh"][f"{name}_{tag}_order"])
+    assert len(nodes) == len(want) == 2 * len(s.prims) - 1
+    for field in ("aabb_min", "aabb_max", "offset", "num_shapes", "axis"):
+        assert np.array_equal(nodes[field], want[field]), field
+
+
+def test_bvh_is_preorder_with_single_shape_leaves(scenes):
+    s = scenes["cornell"]
+    assert len(s.nodes) == 71 and len(s.prims) == 36       # what the reference reports for cornell.json
+    leaves = s.nodes[s.nodes["num_shapes"] > 0]
+    assert (leaves["num_shapes"] == 1).all()
+    assert sorted(leaves["offset"].tolist()) == list(range(36))
+    inner = np.flatnonzero(s.nodes["num_shapes"] == 0)
+    assert (s.nodes["offset"][inner] > inner + 1).all()
+
+
+def test_bvh_degenerate_centroids_terminate():
+    """Equal centroids make the reference recurse without end (src/bvh.cpp:173-175); the host builder splits
+    the range in half instead."""
+    boxes = np.tile(np.array([[0, 0, 0, 1, 1, 1]], np.float32), (9, 1))
+    nodes, order = host.build_bvh(boxes, abi.PTH_SPLIT_SAH)
+    assert len(nodes) == 17 and sorted(order.tolist()) == list(range(9))
+
+
+def write_tga(path, rgba):
+    h, w, _ = rgba.shape
+    hdr = bytearray(18)
+    hdr[2], hdr[12], hdr[13], hdr[14], hdr[15], hdr[16], hdr[17] = 2, w & 255, w >> 8, h & 255, h >> 8, 32, 0x28
+    with open(path, "wb") as f:
+        f.write(bytes(hdr) + rgba[:, :, [2, 1, 0, 3]].tobytes())
+
+
+SCENE = '''{
+ "OutputImageData": { "resolution": [ 20, 10 ], "filename": "out.png" },
+ "Camera": { "position": [ 0, 1, 4 ], "rotation": [ -10, 0, 0 ], "vfov": 60, "aspectRatio": 2, "exposure": 1.5, "gamma": 2.0, "antialiasing": "NONE" },
+ "BVH": { "splitMethod": "EqualCounts" },
+ "MaxDepth": 3, "SamplesPerPixel": [ 2, 8 ], "SamplesPerAreaLight": 2,
+ "NotAKey": { "x": 1 },
+ "BackgroundColor": { "color": [ 0.1, 0.2, 0.3 ] },
+ "PointLight": { "position": [ 0, 3, 0 ], "Lemit": [ 9, 9, 9 ] },
+ "Texture": { "name": "checker", "filename": "tex/checker.tga", "flipVertically": false },
+ "Material": { "name": "a", "albedo": [ 1, 0, 0 ] },
+ "Material": { "name": "b", "albedo": [ 0, 1, 0 ], "albedoTexture": "checker" },
+ "Model": { "name": "quad", "filename": "quad.obj" },
+ "ModelInstance": { "model": "quad", "material": "a", "transform": { "scale": [ 4, 4, 4 ] } },
+ "ModelInstance": { "model": "quad", "material": "b", "transform": { "position": [ 0, 1, 0 ], "rotation": [ 0, 0, 90 ] } },
+ "ModelInstance": { "model": "quad" },
+ "Sphere": { "material": "a", "position": [ 1, 1, 0 ], "radius": 0.5 }
+}'''
+
+QUAD = """mtllib quad.mtl
+v -1 0 1
+v 1 0 1
+v 1 0 -1
+v -1 0 -1
+vt 0 0
+vt 1 0
+vt 1 1
+vt 0 1
+usemtl glow
+f 1/1 2/2 3/3 4/4
+"""
+
+
+def test_scene_file_loader(tmp_path, capfd):
+    os.makedirs(tmp_path / "tex")
+    px = np.zeros((4, 4, 4), np.uint8)
+    px[..., 3] = 255
+    px[0, 0, :3] = (255, 0, 0)
+    write_tga(str(tmp_path / "tex" / "checker.tga"), px)
+    (tmp_path / "quad.obj").write_text(QUAD)
+    (tmp_path / "quad.mtl").write_text("newmtl glow\nKd 0.5 0.5 0.5\nKe 3 2 1\n")
+    (tmp_path / "scene.json").write_text(SCENE)
+    hs = host.HostScene.from_file(str(tmp_path / "scene.json"), str(tmp_path) + "/")
+    out = capfd.readouterr().out
+    assert "WARNING  'NotAKey' not found in mapping" in out      # src/utils/json_parsing.hpp:52-55
+    s = hs.to_data()
+    info = hs.info()
+    assert info["spp"] == [2, 8] and info["output_filename"] == "out.png" and info["split_method"] == abi.PTH_SPLIT_EQUAL_COUNTS
+    assert (s.image_width, s.image_height, s.max_depth) == (20, 10, 3)
+    assert np.allclose(s.background_radiance, [0.1, 0.2, 0.3])
+    assert np.isclose(s.camera["vfov"], np.radians(60)) and s.camera["aspect_ratio"] == 2 and s.camera["gamma"] == 2
+    # three instances of a 2-triangle quad + one sphere; the third instance keeps the emissive MTL material,
+    # which makes one area light per triangle, each with SamplesPerAreaLight samples (src/scene.cpp:333-339)
+    assert len(s.triangles) == 6 and len(s.spheres) == 1 and len(s.prims) == 7 and len(s.nodes) == 13
+    assert s.lights["type"].tolist() == [abi.PT_LIGHT_POINT, abi.PT_LIGHT_AREA, abi.PT_LIGHT_AREA]
+    assert s.lights["n_samples"].tolist() == [1, 2, 2]
+    for l in s.lights[1:]:
+        p = s.prims[l["prim"]]
+        assert p["type"] == abi.PT_PRIM_TRIANGLE and s.meshes[s.triangles[p["index"]]["mesh"]]["material"] == 2
+    # materials in order of definition: "a", "b" from the scene file, then "glow" from quad.mtl
+    assert np.allclose(s.materials["Ke"][2], [3, 2, 1]) and s.materials["albedo_texture"].tolist() == [-1, 0, -1]
+    assert s.textures[0]["width"] == 4 and s.texels[0].tolist() == [255, 0, 0, 255]   # flipVertically false: row 0 first
+    # the first instance is the quad scaled by 4 in the y = 0 plane
+    v = s.vertices[:4]
+    assert np.allclose(np.abs(v[:, [0, 2]]), 4) and np.allclose(v[:, 1], 0)
+    assert np.allclose(s.normals[:4], [0, 1, 0])
+    assert s.draws_per_bounce() == 2 * 4 + 2
+
+
+def test_missing_model_is_an_error_not_a_crash(tmp_path):
+    (tmp_path / "scene.json").write_text('{ "ModelInstance": { "model": "nope" } }')
+    with pytest.raises(host.HostError, match="nope"):
+        host.HostScene.from_file(str(tmp_path / "scene.json"), str(tmp_path) + "/")
+    with pytest.raises(host.HostError):
+        host.HostScene.from_file(str(tmp_path / "absent.json"), str(tmp_path) + "/")
+
+
+def test_procedural_scenes_have_the_requested_size():
+    a = host.HostScene.atrium(seed=1, triangles=20000, texture_size=16).to_data()
+    assert len(a.prims) == 20000 and len(a.nodes) == 39999 and len(a.textures) == 24
+    assert a.lights["type"].tolist() == [abi.PT_LIGHT_DIRECTIONAL] and np.allclose(a.lights["Lemit"][0], [12, 10, 8])
+    assert np.allclose(a.camera["position"], [-9, 2, 0]) and np.allclose(a.camera["view_dir"], [1, 0, 0], atol=1e-6)
+    assert np.isfinite(a.vertices).all() and np.isfinite(a.normals).all() and np.isfinite(a.tangents).all()
+    b = host.HostScene.atrium(seed=1, triangles=20000, texture_size=16).to_data()
+    assert np.array_equal(a.vertices, b.vertices) and np.array_equal(a.nodes, b.nodes)   # deterministic
+    k = host.HostScene.knot(seed=2, triangles=5000).to_data()
+    assert len(k.prims) == 5000 and k.max_depth == 1
+    s = host.HostScene.soup(seed=3, triangles=3000, edge=0.05, skybox_size=8).to_data()
+    assert len(s.prims) == 3000 and s.skybox.size == 6 * 8 * 8 * 4 and s.skybox.max() <= 1.0
+
+
+def test_image_writer_quantises_like_the_reference(tmp_path):
+    """255 * clamp(c, 0, 1) truncated (src/image.cpp:57-68); PNG/TGA/BMP/PPM writers produce readable files."""
+    rgb = np.array([[[0.0, 0.5, 1.0], [1.5, -0.2, 0.999]], [[0.25, 0.75, 0.1], [0.2, 0.3, 0.4]]], np.float32)
+    want = np.array([[[0, 127, 255], [255, 0, 254]], [[63, 191, 25], [51, 76, 102]]], np.uint8)
+    ppm = tmp_path / "o.ppm"
+    host.write_image(str(ppm), rgb)
+    data = ppm.read_bytes()
+    assert data.startswith(b"P6\n2 2\n255\n") and np.array_equal(np.frombuffer(data[-12:], np.uint8).reshape(2, 2, 3), want)
+    for ext in ("png", "tga", "bmp"):
+        f = tmp_path / f"o.{ext}"
+        host.write_image(str(f), rgb)
+        assert f.stat().st_size > 12
+    png = (tmp_path / "o.png").read_bytes()
+    assert png[:8] == b"\x89PNG\r\n\x1a\n"
+    import zlib
+    idat = png[png.index(b"IDAT") + 4: png.index(b"IEND") - 8]
+    raw = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(2, 7)
+    assert np.array_equal(raw[:, 1:].reshape(2, 2, 3), want)
+    with pytest.raises(host.HostError):
+        host.write_image(str(tmp_path / "o.xyz"), rgb)
