@@ -416,18 +416,122 @@ __global__ __launch_bounds__( kBlock ) void RaygenKernel( CameraFrame cam, RngPa
     }
 }
 
+// Wave-level scheduling of the traversal kernels.
+//
+// Rays differ widely in the number of nodes they visit, and a leaf turns up in some lane at almost every step.
+// A lane-per-ray loop therefore runs with most of the 64 lanes masked off: the wave waits for its longest ray,
+// and every step pays for the primitive test of the few lanes that sit at a leaf.  Here every lane is a small
+// state machine - traversing, waiting at a leaf, or waiting for a ray - and the WAVE decides what to do next:
+//   refill    lanes without a ray store their result and take their next ray (ray i, i + stride, ... of the
+//             queue, a static assignment: no atomics), once kRefillLanes lanes are waiting
+//   leaf      lanes waiting at a leaf run the primitive tests together, once kLeafLanes lanes are waiting
+//   traverse  otherwise: up to kTraverseBurst node visits for the traversing lanes
+// A phase also runs as soon as nothing else can make progress, so every lane terminates.  Per ray the sequence
+// of node visits and primitive tests is unchanged: a waiting lane does nothing, it never runs ahead.
+constexpr int kRefillLanes    = 16;
+constexpr int kLeafLanes      = 12;
+constexpr int kTraverseBurst  = 6;
+constexpr uint32_t kNoRay     = 0xFFFFFFFFu;
+
 __global__ __launch_bounds__( kBlock ) void ExtendKernel( SceneView sv, PathBuffers pb, const uint32_t* queue, const uint32_t* countPtr,
                                                          uint32_t fixedCount, uint64_t* stats )
 {
-    const uint32_t count = countPtr ? *countPtr : fixedCount;
+    const uint32_t count  = countPtr ? *countPtr : fixedCount;
+    const uint32_t stride = gridDim.x * kBlock;
+    const uint32_t end    = sv.numNodes;
+    uint32_t next = blockIdx.x * kBlock + threadIdx.x; // queue position of this lane's next ray
+    uint32_t p = kNoRay, node = end, leaf = kInnerNode, leafEscape = end;
+    f3 o = F3( 0.0f, 0.0f, 0.0f ), d = o, inv = o;
+    bool nx = false, ny = false, nz = false;
+    HitRecord h{ FLT_MAX, 0.0f, 0.0f, -1 };
     Counters cnt;
-    for ( uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < count; i += gridDim.x * kBlock )
+
+    for ( ;; )
     {
-        const uint32_t p = queue ? queue[i] : i;
-        const float4 o = pb.rayO[p], d = pb.rayD[p];
-        HitRecord h = TraceClosest( sv, F3( o ), F3( d ), cnt );
-        cnt.rays++;
-        pb.hit[p] = make_float4( h.t, h.u, h.v, __int_as_float( h.prim ) );
+        const bool atLeaf     = leaf != kInnerNode;
+        const bool traversing = node != end && !atLeaf;
+        const bool wantsRay   = node == end && !atLeaf && ( p != kNoRay || next < count );
+        const unsigned long long mLeaf = __ballot( atLeaf ), mTrav = __ballot( traversing ), mRay = __ballot( wantsRay );
+        if ( ( mLeaf | mTrav | mRay ) == 0 ) break;
+
+        if ( mRay && ( __popcll( mRay ) >= kRefillLanes || ( mTrav | mLeaf ) == 0 ) )
+        {
+            if ( wantsRay )
+            {
+                if ( p != kNoRay ) pb.hit[p] = make_float4( h.t, h.u, h.v, __int_as_float( h.prim ) );
+                p = kNoRay;
+                if ( next < count )
+                {
+                    p = queue ? queue[next] : next;
+                    next += stride;
+                    o   = F3( pb.rayO[p] );
+                    d   = F3( pb.rayD[p] );
+                    inv = F3( 1.0f / d.x, 1.0f / d.y, 1.0f / d.z ); // bvh.cpp:235-236
+                    nx = inv.x < 0; ny = inv.y < 0; nz = inv.z < 0;
+                    h    = HitRecord{ FLT_MAX, 0.0f, 0.0f, -1 };     // scene.cpp:372
+                    node = 0;
+                    cnt.rays++;
+                }
+            }
+            continue;
+        }
+
+        if ( mLeaf && ( __popcll( mLeaf ) >= kLeafLanes || mTrav == 0 ) )
+        {
+            if ( atLeaf )
+            {
+                const uint32_t first = leaf & kLeafFirstMask, shapes = ( leaf >> 28 ) + 1;
+                for ( uint32_t k = 0; k < shapes; ++k ) // bvh.cpp:247-250: every shape of the leaf, t shrinking
+                {
+                    const uint32_t prim = first + k;
+                    const float4 q0 = sv.prims[3 * prim], q1 = sv.prims[3 * prim + 1];
+                    float t, u = 0.0f, v = 0.0f;
+                    bool hit;
+                    if ( __float_as_uint( q0.w ) == kTagTriangle )
+                    {
+                        const float4 q2 = sv.prims[3 * prim + 2];
+                        cnt.tris++;
+                        hit = RayTriangle( o, d, F3( q0 ), F3( q1 ), F3( q2 ), h.t, &t, &u, &v );
+                    }
+                    else
+                    {
+                        const float4* s = sv.spheres + 6 * __float_as_uint( q1.y );
+                        const float4 c0 = s[0], c1 = s[1], c2 = s[2], c3 = s[3];
+                        cnt.spheres++;
+                        f3 lo = MatMul( c0, c1, c2, c3, o, 1.0f );
+                        f3 ld = MatMul( c0, c1, c2, c3, d, 0.0f );
+                        hit   = RaySphere( lo, ld, F3( 0.0f, 0.0f, 0.0f ), 1.0f, h.t, &t );
+                    }
+                    if ( hit ) h = HitRecord{ t, u, v, static_cast< int >( prim ) };
+                }
+                node = leafEscape;
+                leaf = kInnerNode;
+            }
+            continue;
+        }
+
+        // traverse: a few node visits in a row; stop early once half of the lanes have dropped out
+        const int started = __popcll( mTrav );
+        for ( int burst = 0; burst < kTraverseBurst; ++burst )
+        {
+            const bool go = node != end && leaf == kInnerNode;
+            if ( go )
+            {
+                const float4 a = sv.nodes[2 * node], b = sv.nodes[2 * node + 1];
+                cnt.nodes++;
+                const uint32_t escape = __float_as_uint( b.z ), word = __float_as_uint( b.w );
+                if ( !RayBox( o, inv, nx, ny, nz, a, b, h.t ) )
+                    node = escape;
+                else if ( word == kInnerNode )
+                    node = node + 1;
+                else
+                {
+                    leaf       = word;
+                    leafEscape = escape;
+                }
+            }
+            if ( 2 * __popcll( __ballot( node != end && leaf == kInnerNode ) ) < started ) break;
+        }
     }
     FlushCounter( stats, ST_RAYS_CLOSEST, cnt.rays );
     FlushCounter( stats, ST_NODES_CLOSEST, cnt.nodes );
