@@ -138,7 +138,8 @@ int Validate( const PtSceneDesc* d, std::vector< uint32_t >& escape )
     if ( d->struct_size != sizeof( PtSceneDesc ) ) return Fail( PT_ERR_INVALID_ARG, "PtSceneDesc::struct_size is %u, expected %zu", d->struct_size, sizeof( PtSceneDesc ) );
     if ( d->version != PT_API_VERSION ) return Fail( PT_ERR_INVALID_ARG, "PtSceneDesc::version is %u, this library implements %u", d->version, PT_API_VERSION );
     if ( !d->nodes || d->num_nodes == 0 || !d->prims || d->num_prims == 0 ) return Fail( PT_ERR_INVALID_SCENE, "scene has no BVH nodes or no primitives" );
-    if ( d->num_prims > kLeafFirstMask ) return Fail( PT_ERR_INVALID_SCENE, "more than %u primitives are not supported", kLeafFirstMask );
+    if ( d->num_prims > kMaxPrims ) return Fail( PT_ERR_INVALID_SCENE, "more than %u primitives are not supported", kMaxPrims );
+    if ( d->num_nodes > kMaxNodes ) return Fail( PT_ERR_INVALID_SCENE, "more than %u BVH nodes are not supported", kMaxNodes );
     if ( d->num_nodes >= 0xFFFFFFFFull ) return Fail( PT_ERR_INVALID_SCENE, "too many BVH nodes" );
     if ( d->image_width <= 0 || d->image_height <= 0 ) return Fail( PT_ERR_INVALID_SCENE, "image size %d x %d", d->image_width, d->image_height );
     if ( static_cast< uint64_t >( d->image_width ) * d->image_height > 0x7fffffffull ) return Fail( PT_ERR_INVALID_SCENE, "image too large" );
@@ -373,6 +374,7 @@ int Upload( PtScene* s, const PtSceneDesc* d, const std::vector< uint32_t >& esc
     v.lights        = s->lights.As< DevLight >();
     v.skybox        = s->skybox.As< float4 >();
     v.numNodes      = N;
+    v.numPrims      = static_cast< uint32_t >( P );
     v.numLights     = static_cast< uint32_t >( d->num_lights );
     v.shadowSlots   = slots;
     v.drawsPerBounce = static_cast< int32_t >( 2 * areaSamples + 2 );

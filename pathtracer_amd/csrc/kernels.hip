@@ -57,6 +57,34 @@ __device__ __forceinline__ float4 F4( f3 a, float w ) { return make_float4( a.x,
 constexpr float kPi      = 3.14159265358979323846f; // src/math.hpp:9-11
 constexpr float kEpsilon = 0.00001f;                // src/path_tracer.cpp:16
 
+// ------------------------------------------------------------------------------------------------ record loads
+// BVH nodes and primitive records are read with buffer_load_dwordx4 through a buffer descriptor: the
+// address is one 32-bit byte offset per lane (no 64-bit address arithmetic), a record is always fetched
+// whole with all of its loads in flight together, and an offset past the end reads zeros instead of faulting.
+typedef uint32_t u32x4 __attribute__( ( ext_vector_type( 4 ) ) );
+using BufferDesc = __amdgpu_buffer_rsrc_t;
+
+__device__ __forceinline__ BufferDesc MakeBuffer( const void* base, uint32_t bytes )
+{
+    return __builtin_amdgcn_make_buffer_rsrc( const_cast< void* >( base ), 0, static_cast< int >( bytes ), 0x00020000 );
+}
+
+__device__ __forceinline__ float4 Load16( BufferDesc buffer, uint32_t byteOffset )
+{
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128( buffer, static_cast< int >( byteOffset ), 0, 0 );
+    return make_float4( __uint_as_float( v.x ), __uint_as_float( v.y ), __uint_as_float( v.z ), __uint_as_float( v.w ) );
+}
+
+struct SceneBuffers
+{
+    BufferDesc nodes, prims;
+};
+
+__device__ __forceinline__ SceneBuffers MakeSceneBuffers( const SceneView& sv )
+{
+    return SceneBuffers{ MakeBuffer( sv.nodes, sv.numNodes * 32u ), MakeBuffer( sv.prims, sv.numPrims * 48u ) };
+}
+
 // std::cos / std::sin of a float in the reference: the host C library's sincosf, reproduced exactly
 __device__ __forceinline__ void SinCosF( float x, float* s, float* c ) { SinCosLibm( x, s, c ); }
 
@@ -125,19 +153,22 @@ __device__ __forceinline__ f3 MatMul( float4 c0, float4 c1, float4 c2, float4 c3
 // NaN slab value behaves as on the CPU.
 __device__ __forceinline__ bool RayBox( f3 o, f3 inv, bool nx, bool ny, bool nz, float4 a, float4 b, float maxT )
 {
+    // Both early returns of the reference are folded into flags: once one of them would have fired the later
+    // values are never looked at, so evaluating everything up front gives the same answer and lets the whole
+    // 32-byte node be fetched with two 16-byte loads before any arithmetic.
     float tMin  = ( ( nx ? a.w : a.x ) - o.x ) * inv.x;
     float tMax  = ( ( nx ? a.x : a.w ) - o.x ) * inv.x;
     float tyMin = ( ( ny ? b.x : a.y ) - o.y ) * inv.y;
     float tyMax = ( ( ny ? a.y : b.x ) - o.y ) * inv.y;
-    if ( tMin > tyMax || tyMin > tMax ) return false;
-    if ( tyMin > tMin ) tMin = tyMin;
-    if ( tyMax < tMax ) tMax = tyMax;
     float tzMin = ( ( nz ? b.y : a.z ) - o.z ) * inv.z;
     float tzMax = ( ( nz ? a.z : b.y ) - o.z ) * inv.z;
-    if ( tMin > tzMax || tzMin > tMax ) return false;
+    const bool missXY = ( tMin > tyMax ) | ( tyMin > tMax );
+    if ( tyMin > tMin ) tMin = tyMin;
+    if ( tyMax < tMax ) tMax = tyMax;
+    const bool missZ = ( tMin > tzMax ) | ( tzMin > tMax );
     if ( tzMin > tMin ) tMin = tzMin;
     if ( tzMax < tMax ) tMax = tzMax;
-    return ( tMin < maxT ) && ( tMax > 0 );
+    return !missXY & !missZ & ( tMin < maxT ) & ( tMax > 0 );
 }
 
 struct HitRecord
@@ -146,9 +177,41 @@ struct HitRecord
     int prim;
 };
 
-// BVH::Intersect (src/bvh.cpp:230-268) + Triangle::Intersect / Sphere::Intersect acceptance
-// (src/shapes.cpp:117-123, 52-61).  Closest hit; the first primitive reaching a given t keeps it (strict <).
-__device__ __forceinline__ HitRecord TraceClosest( const SceneView& sv, f3 o, f3 d, Counters& cnt )
+// One primitive test of a closest-hit leaf: Triangle::Intersect / Sphere::Intersect (src/shapes.cpp:117-123,
+// 52-61).  The 48-byte record is fetched whole before its tag is looked at (one memory round trip); the
+// triangle arithmetic runs on whatever was fetched and is discarded for a sphere record.
+__device__ __forceinline__ void ClosestPrimTest( const SceneView& sv, const SceneBuffers& sb, uint32_t prim, f3 o, f3 d, HitRecord& h, bool* wasSphere )
+{
+    const float4 q0 = Load16( sb.prims, 48u * prim ), q1 = Load16( sb.prims, 48u * prim + 16u ), q2 = Load16( sb.prims, 48u * prim + 32u );
+    float t = 0.0f, u = 0.0f, v = 0.0f;
+    bool hit   = RayTriangle( o, d, F3( q0 ), F3( q1 ), F3( q2 ), h.t, &t, &u, &v );
+    *wasSphere = __float_as_uint( q0.w ) != kTagTriangle;
+    if ( *wasSphere )
+    {
+        // closest-hit sphere test runs in the sphere's local space against the unit sphere
+        const float4* s = sv.spheres + 6 * __float_as_uint( q1.y );
+        const float4 c0 = s[0], c1 = s[1], c2 = s[2], c3 = s[3];
+        f3 lo = MatMul( c0, c1, c2, c3, o, 1.0f );
+        f3 ld = MatMul( c0, c1, c2, c3, d, 0.0f );
+        u = v = 0.0f;
+        hit   = RaySphere( lo, ld, F3( 0.0f, 0.0f, 0.0f ), 1.0f, h.t, &t );
+    }
+    if ( hit ) h = HitRecord{ t, u, v, static_cast< int >( prim ) };
+}
+
+// One primitive test of an any-hit leaf: TestIfHit (src/shapes.cpp:78-82, 136-141), spheres in world space.
+__device__ __forceinline__ bool AnyPrimTest( const SceneBuffers& sb, uint32_t prim, f3 o, f3 d, float tMax, bool* wasSphere )
+{
+    const float4 q0 = Load16( sb.prims, 48u * prim ), q1 = Load16( sb.prims, 48u * prim + 16u ), q2 = Load16( sb.prims, 48u * prim + 32u );
+    float t = 0.0f, u, v;
+    bool hit   = RayTriangle( o, d, F3( q0 ), F3( q1 ), F3( q2 ), tMax, &t, &u, &v );
+    *wasSphere = __float_as_uint( q0.w ) != kTagTriangle;
+    if ( *wasSphere ) hit = RaySphere( o, d, F3( q0 ), q1.x, tMax, &t );
+    return hit;
+}
+
+// BVH::Intersect (src/bvh.cpp:230-268).  Closest hit; the first primitive reaching a given t keeps it (strict <).
+__device__ __forceinline__ HitRecord TraceClosest( const SceneView& sv, const SceneBuffers& sb, f3 o, f3 d, Counters& cnt )
 {
     HitRecord h{ FLT_MAX, 0.0f, 0.0f, -1 };
     const f3 inv  = F3( 1.0f / d.x, 1.0f / d.y, 1.0f / d.z );
@@ -157,57 +220,31 @@ __device__ __forceinline__ HitRecord TraceClosest( const SceneView& sv, f3 o, f3
     uint32_t node = 0;
     while ( node != end )
     {
-        const float4 a = sv.nodes[2 * node], b = sv.nodes[2 * node + 1];
+        const float4 a = Load16( sb.nodes, 32u * node ), b = Load16( sb.nodes, 32u * node + 16u );
         cnt.nodes++;
         const uint32_t escape = __float_as_uint( b.z ), leaf = __float_as_uint( b.w );
-        if ( !RayBox( o, inv, nx, ny, nz, a, b, h.t ) )
-        {
-            node = escape;
-            continue;
-        }
-        if ( leaf == kInnerNode )
+        const bool boxHit = RayBox( o, inv, nx, ny, nz, a, b, h.t );
+        if ( boxHit && leaf == kInnerNode )
         {
             node = node + 1;
             continue;
         }
+        node = escape;
+        if ( !boxHit ) continue;
         const uint32_t first = leaf & kLeafFirstMask, count = ( leaf >> 28 ) + 1;
         for ( uint32_t k = 0; k < count; ++k )
         {
-            const uint32_t prim = first + k;
-            const float4 q0 = sv.prims[3 * prim], q1 = sv.prims[3 * prim + 1];
-            float t, u = 0.0f, v = 0.0f;
-            bool hit;
-            if ( __float_as_uint( q0.w ) == kTagTriangle )
-            {
-                const float4 q2 = sv.prims[3 * prim + 2];
-                cnt.tris++;
-                hit = RayTriangle( o, d, F3( q0 ), F3( q1 ), F3( q2 ), h.t, &t, &u, &v );
-            }
-            else
-            {
-                // closest-hit sphere test runs in the sphere's local space against the unit sphere
-                const float4* s = sv.spheres + 6 * __float_as_uint( q1.y );
-                const float4 c0 = s[0], c1 = s[1], c2 = s[2], c3 = s[3];
-                cnt.spheres++;
-                f3 lo = MatMul( c0, c1, c2, c3, o, 1.0f );
-                f3 ld = MatMul( c0, c1, c2, c3, d, 0.0f );
-                hit   = RaySphere( lo, ld, F3( 0.0f, 0.0f, 0.0f ), 1.0f, h.t, &t );
-            }
-            if ( hit )
-            {
-                h.t    = t;
-                h.u    = u;
-                h.v    = v;
-                h.prim = static_cast< int >( prim );
-            }
+            bool wasSphere;
+            ClosestPrimTest( sv, sb, first + k, o, d, h, &wasSphere );
+            cnt.tris += wasSphere ? 0 : 1;
+            cnt.spheres += wasSphere ? 1 : 0;
         }
-        node = escape;
     }
     return h;
 }
 
-// BVH::Occluded (src/bvh.cpp:270-310) + TestIfHit (src/shapes.cpp:78-82, 136-141): spheres in world space.
-__device__ __forceinline__ bool TraceAny( const SceneView& sv, f3 o, f3 d, float tMax, Counters& cnt )
+// BVH::Occluded (src/bvh.cpp:270-310).
+__device__ __forceinline__ bool TraceAny( const SceneView& sv, const SceneBuffers& sb, f3 o, f3 d, float tMax, Counters& cnt )
 {
     const f3 inv  = F3( 1.0f / d.x, 1.0f / d.y, 1.0f / d.z );
     const bool nx = inv.x < 0, ny = inv.y < 0, nz = inv.z < 0;
@@ -215,38 +252,26 @@ __device__ __forceinline__ bool TraceAny( const SceneView& sv, f3 o, f3 d, float
     uint32_t node = 0;
     while ( node != end )
     {
-        const float4 a = sv.nodes[2 * node], b = sv.nodes[2 * node + 1];
+        const float4 a = Load16( sb.nodes, 32u * node ), b = Load16( sb.nodes, 32u * node + 16u );
         cnt.nodes++;
         const uint32_t escape = __float_as_uint( b.z ), leaf = __float_as_uint( b.w );
-        if ( !RayBox( o, inv, nx, ny, nz, a, b, tMax ) )
-        {
-            node = escape;
-            continue;
-        }
-        if ( leaf == kInnerNode )
+        const bool boxHit = RayBox( o, inv, nx, ny, nz, a, b, tMax );
+        if ( boxHit && leaf == kInnerNode )
         {
             node = node + 1;
             continue;
         }
+        node = escape;
+        if ( !boxHit ) continue;
         const uint32_t first = leaf & kLeafFirstMask, count = ( leaf >> 28 ) + 1;
         for ( uint32_t k = 0; k < count; ++k )
         {
-            const uint32_t prim = first + k;
-            const float4 q0 = sv.prims[3 * prim], q1 = sv.prims[3 * prim + 1];
-            float t, u, v;
-            if ( __float_as_uint( q0.w ) == kTagTriangle )
-            {
-                const float4 q2 = sv.prims[3 * prim + 2];
-                cnt.tris++;
-                if ( RayTriangle( o, d, F3( q0 ), F3( q1 ), F3( q2 ), tMax, &t, &u, &v ) ) return true;
-            }
-            else
-            {
-                cnt.spheres++;
-                if ( RaySphere( o, d, F3( q0 ), q1.x, tMax, &t ) ) return true;
-            }
+            bool wasSphere;
+            const bool hit = AnyPrimTest( sb, first + k, o, d, tMax, &wasSphere );
+            cnt.tris += wasSphere ? 0 : 1;
+            cnt.spheres += wasSphere ? 1 : 0;
+            if ( hit ) return true;
         }
-        node = escape;
     }
     return false;
 }
@@ -433,18 +458,28 @@ constexpr int kLeafLanes      = 12;
 constexpr int kTraverseBurst  = 6;
 constexpr uint32_t kNoRay     = 0xFFFFFFFFu;
 
+// Adds a wave-uniform count to a statistics slot: one atomic per wave, issued by its first lane.
+__device__ __forceinline__ void FlushWaveCounter( uint64_t* stats, int slot, uint32_t waveTotal )
+{
+    if ( ( threadIdx.x & 63 ) == 0 && waveTotal ) atomicAdd( reinterpret_cast< unsigned long long* >( stats + slot ), static_cast< unsigned long long >( waveTotal ) );
+}
+
+__device__ __forceinline__ uint32_t LanesSet( bool flag ) { return static_cast< uint32_t >( __popcll( __ballot( flag ) ) ); }
+
 __global__ __launch_bounds__( kBlock ) void ExtendKernel( SceneView sv, PathBuffers pb, const uint32_t* queue, const uint32_t* countPtr,
                                                          uint32_t fixedCount, uint64_t* stats )
 {
     const uint32_t count  = countPtr ? *countPtr : fixedCount;
     const uint32_t stride = gridDim.x * kBlock;
     const uint32_t end    = sv.numNodes;
+    const SceneBuffers sb = MakeSceneBuffers( sv );
     uint32_t next = blockIdx.x * kBlock + threadIdx.x; // queue position of this lane's next ray
-    uint32_t p = kNoRay, node = end, leaf = kInnerNode, leafEscape = end;
+    // node: the node to visit next (or, while a leaf is pending, the node to go to after it); leaf: pending leaf word
+    uint32_t p = kNoRay, node = end, leaf = kInnerNode;
     f3 o = F3( 0.0f, 0.0f, 0.0f ), d = o, inv = o;
     bool nx = false, ny = false, nz = false;
     HitRecord h{ FLT_MAX, 0.0f, 0.0f, -1 };
-    Counters cnt;
+    uint32_t waveRays = 0, waveNodes = 0, waveTris = 0, waveSpheres = 0; // whole-wave totals, wave-uniform
 
     for ( ;; )
     {
@@ -456,6 +491,7 @@ __global__ __launch_bounds__( kBlock ) void ExtendKernel( SceneView sv, PathBuff
 
         if ( mRay && ( __popcll( mRay ) >= kRefillLanes || ( mTrav | mLeaf ) == 0 ) )
         {
+            bool loaded = false;
             if ( wantsRay )
             {
                 if ( p != kNoRay ) pb.hit[p] = make_float4( h.t, h.u, h.v, __int_as_float( h.prim ) );
@@ -470,73 +506,58 @@ __global__ __launch_bounds__( kBlock ) void ExtendKernel( SceneView sv, PathBuff
                     nx = inv.x < 0; ny = inv.y < 0; nz = inv.z < 0;
                     h    = HitRecord{ FLT_MAX, 0.0f, 0.0f, -1 };     // scene.cpp:372
                     node = 0;
-                    cnt.rays++;
+                    loaded = true;
                 }
             }
+            waveRays += LanesSet( loaded );
             continue;
         }
 
         if ( mLeaf && ( __popcll( mLeaf ) >= kLeafLanes || mTrav == 0 ) )
         {
-            if ( atLeaf )
+            const uint32_t first = leaf & kLeafFirstMask, shapes = atLeaf ? ( leaf >> 28 ) + 1 : 0;
+            for ( uint32_t k = 0; __ballot( k < shapes ) != 0; ++k ) // bvh.cpp:247-250: every shape of the leaf, t shrinking
             {
-                const uint32_t first = leaf & kLeafFirstMask, shapes = ( leaf >> 28 ) + 1;
-                for ( uint32_t k = 0; k < shapes; ++k ) // bvh.cpp:247-250: every shape of the leaf, t shrinking
+                bool isTri = false, isSphere = false;
+                if ( k < shapes )
                 {
-                    const uint32_t prim = first + k;
-                    const float4 q0 = sv.prims[3 * prim], q1 = sv.prims[3 * prim + 1];
-                    float t, u = 0.0f, v = 0.0f;
-                    bool hit;
-                    if ( __float_as_uint( q0.w ) == kTagTriangle )
-                    {
-                        const float4 q2 = sv.prims[3 * prim + 2];
-                        cnt.tris++;
-                        hit = RayTriangle( o, d, F3( q0 ), F3( q1 ), F3( q2 ), h.t, &t, &u, &v );
-                    }
-                    else
-                    {
-                        const float4* s = sv.spheres + 6 * __float_as_uint( q1.y );
-                        const float4 c0 = s[0], c1 = s[1], c2 = s[2], c3 = s[3];
-                        cnt.spheres++;
-                        f3 lo = MatMul( c0, c1, c2, c3, o, 1.0f );
-                        f3 ld = MatMul( c0, c1, c2, c3, d, 0.0f );
-                        hit   = RaySphere( lo, ld, F3( 0.0f, 0.0f, 0.0f ), 1.0f, h.t, &t );
-                    }
-                    if ( hit ) h = HitRecord{ t, u, v, static_cast< int >( prim ) };
+                    ClosestPrimTest( sv, sb, first + k, o, d, h, &isSphere );
+                    isTri = !isSphere;
                 }
-                node = leafEscape;
-                leaf = kInnerNode;
+                waveTris += LanesSet( isTri );
+                waveSpheres += LanesSet( isSphere );
             }
+            leaf = kInnerNode;
             continue;
         }
 
         // traverse: a few node visits in a row; stop early once half of the lanes have dropped out
-        const int started = __popcll( mTrav );
+        const uint32_t started = static_cast< uint32_t >( __popcll( mTrav ) );
         for ( int burst = 0; burst < kTraverseBurst; ++burst )
         {
             const bool go = node != end && leaf == kInnerNode;
+            const uint32_t active = LanesSet( go );
+            if ( burst && 2 * active < started ) break;
+            waveNodes += active;
             if ( go )
             {
-                const float4 a = sv.nodes[2 * node], b = sv.nodes[2 * node + 1];
-                cnt.nodes++;
+                const float4 a = Load16( sb.nodes, 32u * node ), b = Load16( sb.nodes, 32u * node + 16u );
                 const uint32_t escape = __float_as_uint( b.z ), word = __float_as_uint( b.w );
-                if ( !RayBox( o, inv, nx, ny, nz, a, b, h.t ) )
-                    node = escape;
-                else if ( word == kInnerNode )
+                const bool boxHit = RayBox( o, inv, nx, ny, nz, a, b, h.t );
+                if ( boxHit && word == kInnerNode )
                     node = node + 1;
                 else
                 {
-                    leaf       = word;
-                    leafEscape = escape;
+                    node = escape;
+                    if ( boxHit ) leaf = word;
                 }
             }
-            if ( 2 * __popcll( __ballot( node != end && leaf == kInnerNode ) ) < started ) break;
         }
     }
-    FlushCounter( stats, ST_RAYS_CLOSEST, cnt.rays );
-    FlushCounter( stats, ST_NODES_CLOSEST, cnt.nodes );
-    FlushCounter( stats, ST_TRI_CLOSEST, cnt.tris );
-    FlushCounter( stats, ST_SPH_CLOSEST, cnt.spheres );
+    FlushWaveCounter( stats, ST_RAYS_CLOSEST, waveRays );
+    FlushWaveCounter( stats, ST_NODES_CLOSEST, waveNodes );
+    FlushWaveCounter( stats, ST_TRI_CLOSEST, waveTris );
+    FlushWaveCounter( stats, ST_SPH_CLOSEST, waveSpheres );
 }
 
 // Appends `value` to a queue for every lane with `flag` set: one atomic per wave.
@@ -769,7 +790,7 @@ __global__ __launch_bounds__( kBlock ) void ConnectKernel( SceneView sv, PathBuf
                 const float4 dir = pb.shDir[rec];
                 if ( dir.w < 0.0f ) continue;
                 cnt.rays++;
-                if ( !TraceAny( sv, o, F3( dir ), dir.w, cnt ) ) Ld = Ld + F3( pb.shEst[rec] );
+                if ( !TraceAny( sv, MakeSceneBuffers( sv ), o, F3( dir ), dir.w, cnt ) ) Ld = Ld + F3( pb.shEst[rec] );
             }
             Ldirect = Ldirect + Ld / static_cast< float >( nSamples );
         }
@@ -857,7 +878,7 @@ __global__ __launch_bounds__( kBlock ) void TraceClosestKernel( SceneView sv, ui
     for ( uint64_t i = static_cast< uint64_t >( blockIdx.x ) * kBlock + threadIdx.x; i < n; i += static_cast< uint64_t >( gridDim.x ) * kBlock )
     {
         Counters cnt;
-        HitRecord h = TraceClosest( sv, F3( origins + 3 * i ), F3( dirs + 3 * i ), cnt );
+        HitRecord h = TraceClosest( sv, MakeSceneBuffers( sv ), F3( origins + 3 * i ), F3( dirs + 3 * i ), cnt );
         if ( prim ) prim[i] = h.prim;
         if ( t ) t[i] = h.t;
         if ( u ) u[i] = h.u;
@@ -873,7 +894,7 @@ __global__ __launch_bounds__( kBlock ) void TraceAnyKernel( SceneView sv, uint64
     for ( uint64_t i = static_cast< uint64_t >( blockIdx.x ) * kBlock + threadIdx.x; i < n; i += static_cast< uint64_t >( gridDim.x ) * kBlock )
     {
         Counters cnt;
-        bool occ = TraceAny( sv, F3( origins + 3 * i ), F3( dirs + 3 * i ), tMax[i], cnt );
+        bool occ = TraceAny( sv, MakeSceneBuffers( sv ), F3( origins + 3 * i ), F3( dirs + 3 * i ), tMax[i], cnt );
         occluded[i] = occ ? 1 : 0;
         if ( nodes ) nodes[i] = cnt.nodes;
         if ( tests ) tests[i] = cnt.tris + cnt.spheres;

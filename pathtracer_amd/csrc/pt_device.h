@@ -20,6 +20,9 @@ namespace ptd
 constexpr uint32_t kInnerNode    = 0xFFFFFFFFu; // DevNode leaf word of an inner node
 constexpr uint32_t kLeafFirstMask = 0x0FFFFFFFu; // leaf word: low 28 bits first primitive, high 4 bits count - 1
 constexpr int kMaxLeafShapes     = 16;
+// nodes and primitive records are read through 32-bit-offset buffer descriptors: each array stays under 4 GiB
+constexpr uint32_t kMaxNodes = 0xFFFFFFFFu / 32u - 1u;
+constexpr uint32_t kMaxPrims = 0xFFFFFFFFu / 48u - 1u;
 constexpr uint32_t kTagTriangle = 0, kTagSphere = 1;
 
 struct DevLight // 144 bytes
@@ -59,6 +62,7 @@ struct SceneView
     const DevLight* lights;
     const float4* skybox; // 6 * w * h texels or nullptr
     uint32_t numNodes;
+    uint32_t numPrims;
     uint32_t numLights;
     int32_t shadowSlots;     // sum of nSamples over all lights
     int32_t drawsPerBounce;  // 2 * (area light samples) + 2
