@@ -15,8 +15,8 @@ PT_LIGHT_POINT, PT_LIGHT_DIRECTIONAL, PT_LIGHT_AREA = 0, 1, 2
 PT_RNG_PHILOX, PT_RNG_TABLE = 0, 1
 PT_TONEMAP_UNCHARTED2, PT_TONEMAP_REINHARD, PT_TONEMAP_NONE = 0, 1, 2
 PT_RENDER_ACCUMULATE, PT_RENDER_PROFILE = 1, 2
-PT_K_RAYGEN, PT_K_EXTEND, PT_K_SHADE, PT_K_CONNECT, PT_K_FILM, PT_K_TONEMAP, PT_K_COUNT = range(7)
-KERNEL_NAMES = ("raygen", "extend", "shade", "connect", "film", "tonemap")
+PT_K_RAYGEN, PT_K_EXTEND, PT_K_SHADE, PT_K_CONNECT, PT_K_FILM, PT_K_TONEMAP, PT_K_RESOLVE, PT_K_COUNT = range(8)
+KERNEL_NAMES = ("raygen", "extend", "shade", "connect", "film", "tonemap", "resolve")
 PTH_SPLIT_SAH, PTH_SPLIT_MIDDLE, PTH_SPLIT_EQUAL_COUNTS = 0, 1, 2
 
 # numpy record types of the array elements

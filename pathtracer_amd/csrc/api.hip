@@ -89,6 +89,7 @@ struct PtScene
     int device = 0;
     hipStream_t stream = nullptr;
     int gridBlocks = 2048;
+    int extendBlocks = 1024, connectBlocks = 1024; // resident grids of the traversal kernels
 
     // scene
     DeviceBuffer nodes, prims, triShade, spheres, materials, textures, texels, lights, skybox;
@@ -98,7 +99,7 @@ struct PtScene
     uint64_t bytesPerPathFixed = 0;
 
     // path state
-    DeviceBuffer rayO, rayD, thr0, thr1, rad, hit, shDir, shEst, queue0, queue1, shadowQueue, counts;
+    DeviceBuffer rayO, rayD, thr0, thr1, rad, hit, shDir, shEst, queue0, queue1, shadowPaths, shadowRays, sphereQueue, counts, cursors;
     PathBuffers paths{};
     DeviceBuffer sampleTable;
 
@@ -375,6 +376,7 @@ int Upload( PtScene* s, const PtSceneDesc* d, const std::vector< uint32_t >& esc
     v.skybox        = s->skybox.As< float4 >();
     v.numNodes      = N;
     v.numPrims      = static_cast< uint32_t >( P );
+    v.numSpheres    = static_cast< uint32_t >( d->num_spheres );
     v.numLights     = static_cast< uint32_t >( d->num_lights );
     v.shadowSlots   = slots;
     v.drawsPerBounce = static_cast< int32_t >( 2 * areaSamples + 2 );
@@ -386,15 +388,16 @@ int Upload( PtScene* s, const PtSceneDesc* d, const std::vector< uint32_t >& esc
     s->width    = d->image_width;
     s->height   = d->image_height;
     s->maxDepth = d->max_depth;
-    // rayO, rayD, thr x2, rad, hit (16 B each), two queues + shadow queue (4 B each), shadow records 32 B per slot
-    s->bytesPerPathFixed = 6 * 16 + 3 * 4 + 32ull * static_cast< uint64_t >( slots > 0 ? slots : 1 );
+    // rayO, rayD, thr x2, rad, hit (16 B each), four path queues (4 B each), per shadow slot a 32 B record and a 4 B queue entry;
+    // the queues' extra round of entries is small against the 24 GiB budget this figure is used for
+    s->bytesPerPathFixed = 6 * 16 + 4 * 4 + 36ull * static_cast< uint64_t >( slots > 0 ? slots : 1 );
 
     const size_t pixels = static_cast< size_t >( s->width ) * s->height;
     HIP_TRY( s->film.Allocate( pixels * 16 ) );
     HIP_TRY( hipMemset( s->film.ptr, 0, pixels * 16 ) );
     HIP_TRY( s->stats.Allocate( ST_COUNT * 8 ) );
     HIP_TRY( hipMemset( s->stats.ptr, 0, ST_COUNT * 8 ) );
-    HIP_TRY( s->counts.Allocate( 2 * 4 * static_cast< size_t >( s->maxDepth > 0 ? s->maxDepth : 1 ) ) );
+    HIP_TRY( s->cursors.Allocate( 2 * 4 * static_cast< size_t >( s->maxDepth > 0 ? s->maxDepth : 1 ) ) );
     return PT_OK;
 }
 
@@ -410,9 +413,15 @@ int EnsurePathBuffers( PtScene* s, uint64_t capacity )
     HIP_TRY( s->hit.Allocate( capacity * 16 ) );
     HIP_TRY( s->shDir.Allocate( capacity * slots * 16 ) );
     HIP_TRY( s->shEst.Allocate( capacity * slots * 16 ) );
-    HIP_TRY( s->queue0.Allocate( capacity * 4 ) );
-    HIP_TRY( s->queue1.Allocate( capacity * 4 ) );
-    HIP_TRY( s->shadowQueue.Allocate( capacity * 4 ) );
+    // one queue segment of kUnitPaths entries per unit of paths, one length per bounce, queue and unit
+    const uint64_t units   = ( capacity + kUnitPaths - 1 ) / kUnitPaths;
+    const uint64_t entries = units * kUnitPaths;
+    HIP_TRY( s->counts.Allocate( kCountsPerBounce * 4 * static_cast< size_t >( s->maxDepth > 0 ? s->maxDepth : 1 ) * units ) );
+    HIP_TRY( s->queue0.Allocate( entries * 4 ) );
+    HIP_TRY( s->queue1.Allocate( entries * 4 ) );
+    HIP_TRY( s->shadowPaths.Allocate( entries * 4 ) );
+    HIP_TRY( s->shadowRays.Allocate( entries * slots * 4 ) );
+    if ( s->view.numSpheres ) HIP_TRY( s->sphereQueue.Allocate( entries * 4 ) );
     PathBuffers& p = s->paths;
     p.rayO        = s->rayO.As< float4 >();
     p.rayD        = s->rayD.As< float4 >();
@@ -424,9 +433,13 @@ int EnsurePathBuffers( PtScene* s, uint64_t capacity )
     p.shEst       = s->shEst.As< float4 >();
     p.queue[0]    = s->queue0.As< uint32_t >();
     p.queue[1]    = s->queue1.As< uint32_t >();
-    p.shadowQueue = s->shadowQueue.As< uint32_t >();
+    p.shadowPaths = s->shadowPaths.As< uint32_t >();
+    p.shadowRays  = s->shadowRays.As< uint32_t >();
+    p.sphereQueue = s->sphereQueue.As< uint32_t >();
     p.counts      = s->counts.As< uint32_t >();
+    p.cursors     = s->cursors.As< uint32_t >();
     p.capacity    = capacity;
+    p.shadowSlots = static_cast< uint32_t >( slots );
     return PT_OK;
 }
 
@@ -501,6 +514,13 @@ int pt_upload_scene( const PtSceneDesc* desc, PtScene** out )
     s->device = desc->device;
     hipDeviceProp_t prop;
     if ( hipGetDeviceProperties( &prop, desc->device ) == hipSuccess && prop.multiProcessorCount > 0 ) s->gridBlocks = prop.multiProcessorCount * 8;
+    {
+        int extendPerCu = 0, connectPerCu = 0;
+        TraversalOccupancy( &extendPerCu, &connectPerCu );
+        const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        s->extendBlocks  = extendPerCu * cus;
+        s->connectBlocks = connectPerCu * cus;
+    }
     hipError_t e = hipStreamCreate( &s->stream );
     if ( e != hipSuccess )
     {
@@ -569,6 +589,12 @@ int pt_render( PtScene* s, const PtRenderParams* p )
         perPass = std::max< uint64_t >( 1, maxPaths / pixels );
     }
     if ( perPass > static_cast< uint64_t >( totalSamples ) ) perPass = totalSamples > 0 ? totalSamples : 1;
+    {
+        const uint64_t slots = s->view.shadowSlots > 0 ? s->view.shadowSlots : 1;
+        if ( perPass * pixels * slots > 0xfffffffeull )
+            return Fail( PT_ERR_INVALID_ARG, "pt_render: %llu samples per pass of %llu pixels with %llu shadow rays per hit exceeds 2^32 shadow records",
+                         (unsigned long long)perPass, (unsigned long long)pixels, (unsigned long long)slots );
+    }
     if ( perPass * pixels > 0x7fffffffull ) return Fail( PT_ERR_INVALID_ARG, "pt_render: %llu samples per pass of %llu pixels exceeds 2^31 paths", (unsigned long long)perPass, (unsigned long long)pixels );
     if ( totalSamples > 0 )
     {
@@ -590,16 +616,17 @@ int pt_render( PtScene* s, const PtRenderParams* p )
     }
 
     const CameraFrame cam = MakeCameraFrame( s->camera, s->width, s->height );
-    const LaunchCfg cfg{ stream, s->gridBlocks };
+    const LaunchCfg cfg{ stream, s->gridBlocks, s->extendBlocks, s->connectBlocks };
     SpanTimer timer{ s, stream, ( p->flags & PT_RENDER_PROFILE ) != 0 };
     uint64_t* stats = s->stats.As< uint64_t >();
-    const PathBuffers& pb = s->paths;
+    PathBuffers pb = s->paths;
 
     for ( int begin = p->sample_begin; begin < p->sample_end; begin += static_cast< int >( perPass ) )
     {
         const uint32_t inPass   = static_cast< uint32_t >( std::min< int >( static_cast< int >( perPass ), p->sample_end - begin ) );
         const uint32_t numPaths = inPass * static_cast< uint32_t >( pixels );
-        HIP_TRY( hipMemsetAsync( s->counts.ptr, 0, s->counts.bytes, stream ) );
+        pb.units = ( numPaths + kUnitPaths - 1 ) / kUnitPaths;
+        HIP_TRY( hipMemsetAsync( s->cursors.ptr, 0, s->cursors.bytes, stream ) );
 
         int span = timer.Begin( PT_K_RAYGEN );
         LaunchRaygen( cfg, cam, rng, pb, s->width, s->height, static_cast< uint32_t >( begin ), numPaths );
@@ -608,18 +635,19 @@ int pt_render( PtScene* s, const PtRenderParams* p )
         if ( s->maxDepth == 0 ) HIP_TRY( hipMemsetAsync( s->rad.ptr, 0, static_cast< size_t >( numPaths ) * 16, stream ) );
         for ( int bounce = 0; bounce < s->maxDepth; ++bounce )
         {
-            const uint32_t* queue    = bounce == 0 ? nullptr : pb.queue[bounce & 1];
-            const uint32_t* countPtr = bounce == 0 ? nullptr : pb.counts + 2 * ( bounce - 1 );
             span = timer.Begin( PT_K_EXTEND );
-            LaunchExtend( cfg, s->view, pb, queue, countPtr, numPaths, stats );
+            LaunchExtend( cfg, s->view, pb, bounce, numPaths, stats );
             timer.End( span );
             span = timer.Begin( PT_K_SHADE );
-            LaunchShade( cfg, s->view, rng, pb, bounce, s->maxDepth, s->width, s->height, static_cast< uint32_t >( begin ), queue, countPtr, numPaths, stats );
+            LaunchShade( cfg, s->view, rng, pb, bounce, s->maxDepth, s->width, s->height, static_cast< uint32_t >( begin ), numPaths, stats );
             timer.End( span );
             if ( s->view.numLights > 0 )
             {
                 span = timer.Begin( PT_K_CONNECT );
                 LaunchConnect( cfg, s->view, pb, bounce, stats );
+                timer.End( span );
+                span = timer.Begin( PT_K_RESOLVE );
+                LaunchResolve( cfg, s->view, pb, bounce );
                 timer.End( span );
             }
         }
@@ -654,7 +682,7 @@ int pt_readback( PtScene* s, uint32_t tonemap, float* rgb_linear, float* rgb_ton
     {
         if ( !s->linearOut.ptr ) HIP_TRY( s->linearOut.Allocate( pixels * 12 ) );
         if ( !s->tonemappedOut.ptr ) HIP_TRY( s->tonemappedOut.Allocate( pixels * 12 ) );
-        const LaunchCfg cfg{ s->stream, s->gridBlocks };
+        const LaunchCfg cfg{ s->stream, s->gridBlocks, s->extendBlocks, s->connectBlocks };
         s->launches[PT_K_TONEMAP]++;
         LaunchTonemap( cfg, s->film.As< float4 >(), rgb_linear ? s->linearOut.As< float >() : nullptr,
                        rgb_tonemapped ? s->tonemappedOut.As< float >() : nullptr, static_cast< uint32_t >( pixels ), s->camera.exposure,
@@ -710,7 +738,7 @@ int pt_trace_closest( PtScene* s, uint64_t n, const float* origins, const float*
     HIP_TRY( dV.Allocate( n * 4 ) );
     HIP_TRY( dN.Allocate( n * 4 ) );
     HIP_TRY( dP.Allocate( n * 4 ) );
-    const LaunchCfg cfg{ s->stream, s->gridBlocks };
+    const LaunchCfg cfg{ s->stream, s->gridBlocks, s->extendBlocks, s->connectBlocks };
     LaunchTraceClosest( cfg, s->view, n, dO.As< float >(), dD.As< float >(), dPrim.As< int32_t >(), dT.As< float >(), dU.As< float >(),
                         dV.As< float >(), dN.As< uint32_t >(), dP.As< uint32_t >() );
     HIP_TRY( hipGetLastError() );
@@ -737,7 +765,7 @@ int pt_trace_any( PtScene* s, uint64_t n, const float* origins, const float* dir
     HIP_TRY( dOcc.Allocate( n ) );
     HIP_TRY( dN.Allocate( n * 4 ) );
     HIP_TRY( dP.Allocate( n * 4 ) );
-    const LaunchCfg cfg{ s->stream, s->gridBlocks };
+    const LaunchCfg cfg{ s->stream, s->gridBlocks, s->extendBlocks, s->connectBlocks };
     LaunchTraceAny( cfg, s->view, n, dO.As< float >(), dD.As< float >(), dT.As< float >(), dOcc.As< uint8_t >(), dN.As< uint32_t >(), dP.As< uint32_t >() );
     HIP_TRY( hipGetLastError() );
     HIP_TRY( hipStreamSynchronize( s->stream ) );

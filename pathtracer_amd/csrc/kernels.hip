@@ -359,9 +359,11 @@ __device__ __forceinline__ f3 UniformSampleSphere( float u1, float u2 )
 __device__ __forceinline__ f3 TextureFetch( const SceneView& sv, int tex, float u, float v )
 {
     const DevTexture t = sv.textures[tex];
-    u = fmodf( u, 1.0f );
+    // fmodf( x, 1 ) is x - trunc( x ), exactly: both have the same sign and exponent range, so the
+    // subtraction does not round; for |x| >= 2^23 both give a zero, and a zero of either sign maps to texel 0
+    u = u - truncf( u );
     u = u < 0 ? u + 1 : u;
-    v = fmodf( v, 1.0f );
+    v = v - truncf( v );
     v = v < 0 ? v + 1 : v;
     int w = static_cast< int >( u * t.width );
     int h = static_cast< int >( v * t.height );
@@ -441,39 +443,101 @@ __global__ __launch_bounds__( kBlock ) void RaygenKernel( CameraFrame cam, RngPa
     }
 }
 
-// Wave-level scheduling of the traversal kernels.
+// ------------------------------------------------------------------------------------------------ work division
 //
-// Rays differ widely in the number of nodes they visit, and a leaf turns up in some lane at almost every step.
-// A lane-per-ray loop therefore runs with most of the 64 lanes masked off: the wave waits for its longest ray,
-// and every step pays for the primitive test of the few lanes that sit at a leaf.  Here every lane is a small
-// state machine - traversing, waiting at a leaf, or waiting for a ray - and the WAVE decides what to do next:
-//   refill    lanes without a ray store their result and take their next ray (ray i, i + stride, ... of the
-//             queue, a static assignment: no atomics), once kRefillLanes lanes are waiting
-//   leaf      lanes waiting at a leaf run the primitive tests together, once kLeafLanes lanes are waiting
-//   traverse  otherwise: up to kTraverseBurst node visits for the traversing lanes
-// A phase also runs as soon as nothing else can make progress, so every lane terminates.  Per ray the sequence
-// of node visits and primitive tests is unchanged: a waiting lane does nothing, it never runs ahead.
-constexpr int kRefillLanes    = 16;
-constexpr int kLeafLanes      = 12;
-constexpr int kTraverseBurst  = 6;
-constexpr uint32_t kNoRay     = 0xFFFFFFFFu;
+// The paths of a pass are cut into units of kUnitPaths consecutive path ids, and every queue into one segment
+// per unit.  Whatever a path appends to a queue goes to the segment of the unit the path started in, and a unit
+// is always processed by ONE wave at a time, so a segment's length is a wave-uniform register while the wave
+// works on it and is written once when the unit is done - no atomics on the queues, no ordering between waves.
+// The shading kernels take one unit per wave (the hardware's block scheduler balances them); the traversal
+// kernels run a fixed number of resident waves, each pulling unit after unit from a shared cursor and feeding
+// its lanes from that stream.
+constexpr uint32_t kNoRay = 0xFFFFFFFFu;
+
+__device__ __forceinline__ uint32_t WaveIndex() { return blockIdx.x * ( kBlock / 64 ) + ( threadIdx.x >> 6 ); }
+__device__ __forceinline__ uint32_t LaneIndex() { return threadIdx.x & 63u; }
+__device__ __forceinline__ uint32_t LanesSet( bool flag ) { return static_cast< uint32_t >( __popcll( __ballot( flag ) ) ); }
+__device__ __forceinline__ uint32_t LanesBelow( unsigned long long mask ) { return static_cast< uint32_t >( __popcll( mask & ( ( 1ull << LaneIndex() ) - 1ull ) ) ); }
+
+__device__ __forceinline__ uint32_t* UnitCount( const PathBuffers& pb, int bounce, int which, uint32_t unit )
+{
+    return pb.counts + ( static_cast< size_t >( bounce ) * kCountsPerBounce + which ) * pb.units + unit;
+}
+
+// Appends `value` to a segment for every lane with `flag` set.  Must be reached by the whole wave (count is
+// wave-uniform).
+__device__ __forceinline__ void SegmentAppend( bool flag, uint32_t value, uint32_t* segment, uint32_t& count )
+{
+    const unsigned long long mask = __ballot( flag );
+    if ( flag ) segment[count + LanesBelow( mask )] = value;
+    count += static_cast< uint32_t >( __popcll( mask ) );
+}
+
+// The stream of queue entries a traversal wave feeds its lanes from: unit after unit, taken from a cursor that
+// all waves of the launch share.  Everything in here is wave-uniform.
+struct UnitStream
+{
+    uint32_t* cursor;       // next unit to hand out
+    const uint32_t* counts; // entries per unit, or null: all paths of the pass (bounce 0)
+    uint32_t numUnits, entriesPerUnit, numPaths;
+    uint32_t base = 0, count = 0, taken = 0; // current unit: first entry, entries, entries handed out
+    bool ended = false;
+};
+
+// Moves on to the next unit; false once the cursor has passed the last one.  Whole wave.
+__device__ __forceinline__ bool NextUnit( UnitStream& s )
+{
+    uint32_t unit = 0;
+    if ( LaneIndex() == 0 ) unit = atomicAdd( s.cursor, 1u );
+    unit = __builtin_amdgcn_readfirstlane( unit );
+    if ( unit >= s.numUnits )
+    {
+        s.ended = true;
+        return false;
+    }
+    s.base  = unit * s.entriesPerUnit;
+    s.taken = 0;
+    if ( s.counts )
+        s.count = s.counts[unit];
+    else
+    {
+        const uint32_t left = s.numPaths - unit * kUnitPaths;
+        s.count = left < kUnitPaths ? left : kUnitPaths;
+    }
+    return true;
+}
 
 // Adds a wave-uniform count to a statistics slot: one atomic per wave, issued by its first lane.
 __device__ __forceinline__ void FlushWaveCounter( uint64_t* stats, int slot, uint32_t waveTotal )
 {
-    if ( ( threadIdx.x & 63 ) == 0 && waveTotal ) atomicAdd( reinterpret_cast< unsigned long long* >( stats + slot ), static_cast< unsigned long long >( waveTotal ) );
+    if ( LaneIndex() == 0 && waveTotal ) atomicAdd( reinterpret_cast< unsigned long long* >( stats + slot ), static_cast< unsigned long long >( waveTotal ) );
 }
 
-__device__ __forceinline__ uint32_t LanesSet( bool flag ) { return static_cast< uint32_t >( __popcll( __ballot( flag ) ) ); }
+// ------------------------------------------------------------------------------------------------ traversal kernels
+//
+// Wave-level scheduling.  Rays differ widely in the number of nodes they visit, and a leaf turns up in some lane
+// at almost every step.  A lane-per-ray loop therefore runs with most of the 64 lanes masked off: the wave waits
+// for its longest ray, and every step pays for the primitive test of the few lanes that sit at a leaf.  Here
+// every lane is a small state machine - traversing, waiting at a leaf, or waiting for a ray - and the WAVE
+// decides what to do next:
+//   refill    lanes without a ray store their result and take the next entries of the wave's stream, once
+//             kRefillLanes lanes are waiting
+//   leaf      lanes waiting at a leaf run the primitive tests together, once kLeafLanes lanes are waiting
+//   traverse  otherwise: up to kTraverseBurst node visits for the traversing lanes
+// A phase also runs as soon as nothing else can make progress, so every lane terminates.  Per ray the sequence
+// of node visits and primitive tests is unchanged: a waiting lane does nothing, it never runs ahead.
+constexpr int kRefillLanes   = 16;
+constexpr int kLeafLanes     = 12;
+constexpr int kTraverseBurst = 6;
 
-__global__ __launch_bounds__( kBlock ) void ExtendKernel( SceneView sv, PathBuffers pb, const uint32_t* queue, const uint32_t* countPtr,
-                                                         uint32_t fixedCount, uint64_t* stats )
+// Closest hits of the rays entering `bounce`: BVH::Intersect (src/bvh.cpp:230-268) under Scene::Intersect
+// (src/scene.cpp:370-373).
+__global__ __launch_bounds__( kBlock ) void ExtendKernel( SceneView sv, PathBuffers pb, int bounce, uint32_t numPaths, uint64_t* stats )
 {
-    const uint32_t count  = countPtr ? *countPtr : fixedCount;
-    const uint32_t stride = gridDim.x * kBlock;
+    UnitStream stream{ pb.cursors + 2 * bounce, bounce == 0 ? nullptr : UnitCount( pb, bounce - 1, kCountNextPaths, 0 ), pb.units, kUnitPaths, numPaths };
+    const uint32_t* items = bounce == 0 ? nullptr : pb.queue[bounce & 1];
     const uint32_t end    = sv.numNodes;
     const SceneBuffers sb = MakeSceneBuffers( sv );
-    uint32_t next = blockIdx.x * kBlock + threadIdx.x; // queue position of this lane's next ray
     // node: the node to visit next (or, while a leaf is pending, the node to go to after it); leaf: pending leaf word
     uint32_t p = kNoRay, node = end, leaf = kInnerNode;
     f3 o = F3( 0.0f, 0.0f, 0.0f ), d = o, inv = o;
@@ -485,31 +549,41 @@ __global__ __launch_bounds__( kBlock ) void ExtendKernel( SceneView sv, PathBuff
     {
         const bool atLeaf     = leaf != kInnerNode;
         const bool traversing = node != end && !atLeaf;
-        const bool wantsRay   = node == end && !atLeaf && ( p != kNoRay || next < count );
+        const bool idle       = node == end && !atLeaf;
+        const bool wantsRay   = idle && ( p != kNoRay || !stream.ended );
         const unsigned long long mLeaf = __ballot( atLeaf ), mTrav = __ballot( traversing ), mRay = __ballot( wantsRay );
         if ( ( mLeaf | mTrav | mRay ) == 0 ) break;
 
         if ( mRay && ( __popcll( mRay ) >= kRefillLanes || ( mTrav | mLeaf ) == 0 ) )
         {
-            bool loaded = false;
-            if ( wantsRay )
+            if ( idle && p != kNoRay ) pb.hit[p] = make_float4( h.t, h.u, h.v, __int_as_float( h.prim ) );
+            if ( idle ) p = kNoRay;
+            while ( !stream.ended )
             {
-                if ( p != kNoRay ) pb.hit[p] = make_float4( h.t, h.u, h.v, __int_as_float( h.prim ) );
-                p = kNoRay;
-                if ( next < count )
+                const unsigned long long mIdle = __ballot( idle && p == kNoRay );
+                if ( mIdle == 0 ) break;
+                if ( stream.taken == stream.count )
                 {
-                    p = queue ? queue[next] : next;
-                    next += stride;
+                    NextUnit( stream );
+                    continue;
+                }
+                const uint32_t left = stream.count - stream.taken, asking = static_cast< uint32_t >( __popcll( mIdle ) );
+                const uint32_t rank = LanesBelow( mIdle );
+                if ( idle && p == kNoRay && rank < left )
+                {
+                    const uint32_t entry = stream.base + stream.taken + rank;
+                    p   = items ? items[entry] : entry;
                     o   = F3( pb.rayO[p] );
                     d   = F3( pb.rayD[p] );
                     inv = F3( 1.0f / d.x, 1.0f / d.y, 1.0f / d.z ); // bvh.cpp:235-236
                     nx = inv.x < 0; ny = inv.y < 0; nz = inv.z < 0;
                     h    = HitRecord{ FLT_MAX, 0.0f, 0.0f, -1 };     // scene.cpp:372
                     node = 0;
-                    loaded = true;
                 }
+                const uint32_t given = asking < left ? asking : left;
+                stream.taken += given;
+                waveRays += given;
             }
-            waveRays += LanesSet( loaded );
             continue;
         }
 
@@ -560,46 +634,173 @@ __global__ __launch_bounds__( kBlock ) void ExtendKernel( SceneView sv, PathBuff
     FlushWaveCounter( stats, ST_SPH_CLOSEST, waveSpheres );
 }
 
-// Appends `value` to a queue for every lane with `flag` set: one atomic per wave.
-__device__ __forceinline__ void WaveAppend( bool flag, uint32_t value, uint32_t* queue, uint32_t* counter )
+// Visibility of the queued shadow rays: BVH::Occluded (src/bvh.cpp:270-310) under Scene::Occluded
+// (src/scene.cpp:381-384), same scheduling as ExtendKernel.  One work item per shadow record; an occluded
+// record gets the distance -2 written back, so that ResolveKernel leaves it out of the sum.
+__global__ __launch_bounds__( kBlock ) void ConnectKernel( SceneView sv, PathBuffers pb, int bounce, uint64_t* stats )
 {
-    const unsigned long long mask = __ballot( flag );
-    if ( mask == 0 ) return;
-    const int lane   = threadIdx.x & 63;
-    const int leader = __ffsll( static_cast< long long >( mask ) ) - 1;
-    uint32_t base = 0;
-    if ( lane == leader ) base = atomicAdd( counter, static_cast< uint32_t >( __popcll( mask ) ) );
-    base = __shfl( base, leader, 64 );
-    if ( flag ) queue[base + __popcll( mask & ( ( 1ull << lane ) - 1ull ) )] = value;
+    UnitStream stream{ pb.cursors + 2 * bounce + 1, UnitCount( pb, bounce, kCountShadowRays, 0 ), pb.units, kUnitPaths * pb.shadowSlots, 0u };
+    const uint32_t end      = sv.numNodes;
+    const uint32_t capacity = static_cast< uint32_t >( pb.capacity );
+    const SceneBuffers sb   = MakeSceneBuffers( sv );
+    uint32_t rec = kNoRay, node = end, leaf = kInnerNode;
+    f3 o = F3( 0.0f, 0.0f, 0.0f ), d = o, inv = o;
+    float tMax = 0.0f;
+    bool nx = false, ny = false, nz = false, occluded = false;
+    uint32_t waveRays = 0, waveNodes = 0, waveTris = 0, waveSpheres = 0; // whole-wave totals, wave-uniform
+
+    for ( ;; )
+    {
+        const bool atLeaf     = leaf != kInnerNode;
+        const bool traversing = node != end && !atLeaf;
+        const bool idle       = node == end && !atLeaf;
+        const bool wantsRay   = idle && ( rec != kNoRay || !stream.ended );
+        const unsigned long long mLeaf = __ballot( atLeaf ), mTrav = __ballot( traversing ), mRay = __ballot( wantsRay );
+        if ( ( mLeaf | mTrav | mRay ) == 0 ) break;
+
+        if ( mRay && ( __popcll( mRay ) >= kRefillLanes || ( mTrav | mLeaf ) == 0 ) )
+        {
+            if ( idle && rec != kNoRay && occluded ) reinterpret_cast< float* >( pb.shDir )[4ull * rec + 3] = -2.0f;
+            if ( idle ) rec = kNoRay;
+            while ( !stream.ended )
+            {
+                const unsigned long long mIdle = __ballot( idle && rec == kNoRay );
+                if ( mIdle == 0 ) break;
+                if ( stream.taken == stream.count )
+                {
+                    NextUnit( stream );
+                    continue;
+                }
+                const uint32_t left = stream.count - stream.taken, asking = static_cast< uint32_t >( __popcll( mIdle ) );
+                const uint32_t rank = LanesBelow( mIdle );
+                if ( idle && rec == kNoRay && rank < left )
+                {
+                    rec = pb.shadowRays[stream.base + stream.taken + rank];
+                    const float4 dir = pb.shDir[rec];
+                    o    = F3( pb.rayO[rec % capacity] );
+                    d    = F3( dir );
+                    tMax = dir.w;
+                    inv  = F3( 1.0f / d.x, 1.0f / d.y, 1.0f / d.z ); // bvh.cpp:275-276
+                    nx = inv.x < 0; ny = inv.y < 0; nz = inv.z < 0;
+                    occluded = false;
+                    node     = 0;
+                }
+                const uint32_t given = asking < left ? asking : left;
+                stream.taken += given;
+                waveRays += given;
+            }
+            continue;
+        }
+
+        if ( mLeaf && ( __popcll( mLeaf ) >= kLeafLanes || mTrav == 0 ) )
+        {
+            const uint32_t first = leaf & kLeafFirstMask;
+            uint32_t shapes = atLeaf ? ( leaf >> 28 ) + 1 : 0;
+            for ( uint32_t k = 0; __ballot( k < shapes ) != 0; ++k ) // bvh.cpp:287-293: stop at the first hit
+            {
+                bool isTri = false, isSphere = false;
+                if ( k < shapes )
+                {
+                    if ( AnyPrimTest( sb, first + k, o, d, tMax, &isSphere ) )
+                    {
+                        occluded = true;
+                        shapes   = 0;
+                        node     = end;
+                    }
+                    isTri = !isSphere;
+                }
+                waveTris += LanesSet( isTri );
+                waveSpheres += LanesSet( isSphere );
+            }
+            leaf = kInnerNode;
+            continue;
+        }
+
+        const uint32_t started = static_cast< uint32_t >( __popcll( mTrav ) );
+        for ( int burst = 0; burst < kTraverseBurst; ++burst )
+        {
+            const bool go = node != end && leaf == kInnerNode;
+            const uint32_t active = LanesSet( go );
+            if ( burst && 2 * active < started ) break;
+            waveNodes += active;
+            if ( go )
+            {
+                const float4 a = Load16( sb.nodes, 32u * node ), b = Load16( sb.nodes, 32u * node + 16u );
+                const uint32_t escape = __float_as_uint( b.z ), word = __float_as_uint( b.w );
+                const bool boxHit = RayBox( o, inv, nx, ny, nz, a, b, tMax );
+                if ( boxHit && word == kInnerNode )
+                    node = node + 1;
+                else
+                {
+                    node = escape;
+                    if ( boxHit ) leaf = word;
+                }
+            }
+        }
+    }
+    FlushWaveCounter( stats, ST_RAYS_SHADOW, waveRays );
+    FlushWaveCounter( stats, ST_NODES_SHADOW, waveNodes );
+    FlushWaveCounter( stats, ST_TRI_SHADOW, waveTris );
+    FlushWaveCounter( stats, ST_SPH_SHADOW, waveSpheres );
 }
 
-__global__ __launch_bounds__( kBlock ) void ShadeKernel( SceneView sv, RngParams rng, PathBuffers pb, int bounce, int maxDepth,
-                                                        uint32_t width, uint32_t height, uint32_t sampleBegin, const uint32_t* queue,
-                                                        const uint32_t* countPtr, uint32_t fixedCount, uint64_t* stats )
+// ------------------------------------------------------------------------------------------------ shading
+
+// What the light loop and the BRDF sampling need from a shaded hit
+struct Surface
 {
-    const uint32_t count     = countPtr ? *countPtr : fixedCount;
+    f3 position, normal, tangent, bitangent;
+    f3 F;  // BRDF::F = Kd / pi
+    f3 wo;
+};
+
+// Shading of the closest hits (path_tracer.cpp:115-152).  Two instances: kSphereHits = false handles misses
+// and triangle hits and defers the paths that hit a sphere to pb.sphereQueue; kSphereHits = true runs over
+// that queue.  The sphere attributes need double precision atan2 / acos / sincos, whose registers would
+// otherwise cap the occupancy of the triangle path that nearly every hit takes.
+template < bool kSphereHits >
+__global__ __launch_bounds__( kBlock ) void ShadeKernel( SceneView sv, RngParams rng, PathBuffers pb, int bounce, int maxDepth,
+                                                        uint32_t width, uint32_t height, uint32_t sampleBegin, uint32_t numPaths, uint64_t* stats )
+{
     const uint32_t numPixels = width * height;
     const int cur = bounce & 1, nxt = cur ^ 1;
-    uint32_t* nextQueue   = pb.queue[nxt];
-    uint32_t* nextCount   = pb.counts + 2 * bounce;
-    uint32_t* shadowCount = pb.counts + 2 * bounce + 1;
-    uint32_t shaded = 0;
+    const uint32_t unit = WaveIndex(); // one unit per wave
+    if ( unit >= pb.units ) return;
+    const uint32_t segment = unit * kUnitPaths;
+    // entries of this unit: its sphere hits, all of its paths (bounce 0), or its paths still alive
+    const uint32_t* items = kSphereHits ? pb.sphereQueue + segment : bounce == 0 ? nullptr : pb.queue[cur] + segment;
+    uint32_t limit;
+    if ( kSphereHits )
+        limit = *UnitCount( pb, bounce, kCountSphereHits, unit );
+    else if ( bounce == 0 )
+        limit = numPaths - segment < kUnitPaths ? numPaths - segment : kUnitPaths;
+    else
+        limit = *UnitCount( pb, bounce - 1, kCountNextPaths, unit );
+    uint32_t* outNext        = pb.queue[nxt] + segment;
+    uint32_t* outShadowPaths = pb.shadowPaths + segment;
+    uint32_t* outShadowRays  = pb.shadowRays + static_cast< size_t >( segment ) * pb.shadowSlots;
+    // the sphere instance continues the segments the triangle instance has started
+    uint32_t nNext        = kSphereHits ? *UnitCount( pb, bounce, kCountNextPaths, unit ) : 0u;
+    uint32_t nShadowPaths = kSphereHits ? *UnitCount( pb, bounce, kCountShadowPaths, unit ) : 0u;
+    uint32_t nShadowRays  = kSphereHits ? *UnitCount( pb, bounce, kCountShadowRays, unit ) : 0u;
+    uint32_t nSpheres = 0, waveShaded = 0;
+    const uint32_t drawBase = 2u + static_cast< uint32_t >( bounce ) * static_cast< uint32_t >( sv.drawsPerBounce );
 
-    // every lane of a wave runs the same number of iterations so that the wave-wide appends stay convergent
-    const uint32_t stride = gridDim.x * kBlock;
-    const uint32_t rounds = ( count + stride - 1 ) / stride;
-    for ( uint32_t round = 0; round < rounds; ++round )
+    for ( uint32_t j = LaneIndex(); __ballot( j < limit ) != 0; j += 64u )
     {
-        const uint32_t i  = round * stride + blockIdx.x * kBlock + threadIdx.x;
-        bool alive = false, anyShadow = false;
-        uint32_t p = 0;
-        if ( i < count )
+        bool lit = false, deferred = false, alive = false, anyShadow = false;
+        uint32_t p = 0, pixel = 0, sample = 0;
+        Surface sf{};
+        f3 T = F3( 0.0f, 0.0f, 0.0f );
+
+        // hit attributes and material
+        if ( j < limit )
         {
-            p = queue ? queue[i] : i;
-            const f3 o = F3( pb.rayO[p] ), d = F3( pb.rayD[p] );
-            const f3 T = F3( pb.thr[cur][p] );
+            p = items ? items[j] : segment + j;
             const float4 hr = pb.hit[p];
             const int prim  = __float_as_int( hr.w );
+            const f3 o = F3( pb.rayO[p] ), d = F3( pb.rayD[p] );
+            T    = F3( pb.thr[cur][p] );
             f3 L = bounce == 0 ? F3( 0.0f, 0.0f, 0.0f ) : F3( pb.rad[p] );
 
             if ( prim < 0 )
@@ -609,24 +810,23 @@ __global__ __launch_bounds__( kBlock ) void ShadeKernel( SceneView sv, RngParams
             }
             else
             {
-                shaded++;
                 const float t = hr.x, u = hr.y, v = hr.z;
-                f3 position = o + d * t; // Ray::Evaluate
-                f3 normal, tangent, bitangent;
+                sf.position = o + d * t; // Ray::Evaluate
                 float tu, tv;
                 int material;
-                const float4 q0 = sv.prims[3 * prim];
-                if ( __float_as_uint( q0.w ) == kTagTriangle )
+                if constexpr ( !kSphereHits )
                 {
-                    // Triangle::Intersect attribute interpolation (src/shapes.cpp:123-130)
+                    // Triangle::Intersect attribute interpolation (src/shapes.cpp:123-130).  The attribute record
+                    // is fetched together with the tag; for a sphere primitive it is all zeros and unused.
                     const float4* a = sv.triShade + 7 * static_cast< size_t >( prim );
                     const float4 a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3], a4 = a[4], a5 = a[5], a6 = a[6];
+                    deferred = sv.numSpheres != 0 && __float_as_uint( sv.prims[3 * prim].w ) != kTagTriangle;
                     const f3 n0 = F3( a0.x, a0.y, a0.z ), n1 = F3( a0.w, a1.x, a1.y ), n2 = F3( a1.z, a1.w, a2.x );
                     const f3 t0 = F3( a2.y, a2.z, a2.w ), t1 = F3( a3.x, a3.y, a3.z ), t2 = F3( a3.w, a4.x, a4.y );
                     const float w = 1 - u - v;
-                    normal    = Normalize( n0 * w + n1 * u + n2 * v );
-                    tangent   = Normalize( t0 * w + t1 * u + t2 * v );
-                    bitangent = Cross( normal, tangent );
+                    sf.normal    = Normalize( n0 * w + n1 * u + n2 * v );
+                    sf.tangent   = Normalize( t0 * w + t1 * u + t2 * v );
+                    sf.bitangent = Cross( sf.normal, sf.tangent );
                     tu        = ( w * a4.z + u * a5.x ) + v * a5.z;
                     tv        = ( w * a4.w + u * a5.y ) + v * a5.w;
                     material  = __float_as_int( a6.x );
@@ -635,162 +835,183 @@ __global__ __launch_bounds__( kBlock ) void ShadeKernel( SceneView sv, RngParams
                 {
                     // Sphere::Intersect (src/shapes.cpp:61-73).  atan2 / sin / cos are the double functions in
                     // the reference's build, acosf the float one.
-                    const float4 q1 = sv.prims[3 * prim + 1];
+                    const float4 q0 = sv.prims[3 * prim], q1 = sv.prims[3 * prim + 1];
                     const float4* s = sv.spheres + 6 * __float_as_uint( q1.y );
                     const float4 c0 = s[0], c1 = s[1], c2 = s[2], c3 = s[3];
-                    normal   = Normalize( position - F3( q0 ) );
-                    f3 lo    = MatMul( c0, c1, c2, c3, o, 1.0f );
-                    f3 ld    = MatMul( c0, c1, c2, c3, d, 0.0f );
-                    f3 lp    = lo + ld * t;
+                    sf.normal = Normalize( sf.position - F3( q0 ) );
+                    f3 lo     = MatMul( c0, c1, c2, c3, o, 1.0f );
+                    f3 ld     = MatMul( c0, c1, c2, c3, d, 0.0f );
+                    f3 lp     = lo + ld * t;
                     float theta = static_cast< float >( atan2( static_cast< double >( lp.z ), static_cast< double >( lp.x ) ) );
                     float phi   = static_cast< float >( acos( static_cast< double >( -lp.y ) ) );
-                    tu       = -0.5f * ( theta / kPi + 1 );
-                    tv       = phi / kPi;
+                    tu        = -0.5f * ( theta / kPi + 1 );
+                    tv        = phi / kPi;
                     double ds, dc;
                     sincos( static_cast< double >( theta ), &ds, &dc );
-                    tangent   = F3( static_cast< float >( -ds ), 0.0f, static_cast< float >( dc ) );
-                    bitangent = Cross( normal, tangent );
+                    sf.tangent   = F3( static_cast< float >( -ds ), 0.0f, static_cast< float >( dc ) );
+                    sf.bitangent = Cross( sf.normal, sf.tangent );
                     material  = __float_as_int( s[5].x );
                 }
-                const f3 wo = -d;
-                position    = position + normal * kEpsilon; // path_tracer.cpp:122
-
-                const float4 m0 = sv.materials[2 * material], m1 = sv.materials[2 * material + 1];
-                if ( bounce == 0 && Dot( wo, normal ) > 0 ) L = L + T * F3( m1 ); // path_tracer.cpp:125-128
-                if ( bounce == 0 ) pb.rad[p] = F4( L, 0.0f );
-
-                f3 Kd = F3( m0 ); // Material::GetAlbedo (src/resource/material.cpp:34-43)
-                const int tex = __float_as_int( m0.w );
-                if ( tex >= 0 ) Kd = Kd * TextureFetch( sv, tex, tu, tv );
-                const f3 F = Kd / kPi; // BRDF::F (src/resource/material.cpp:15-18)
-
-                // LDirect / EstimateSingleDirect (path_tracer.cpp:74-104): one shadow record per light sample.
-                // The visibility test and the sum happen in ConnectKernel.
-                const uint32_t pixel = p % numPixels, sample = sampleBegin + p / numPixels;
-                const uint32_t drawBase = 2u + static_cast< uint32_t >( bounce ) * static_cast< uint32_t >( sv.drawsPerBounce );
-                int slot = 0;
-                for ( uint32_t li = 0; li < sv.numLights; ++li )
+                if ( !deferred )
                 {
-                    const DevLight& l = sv.lights[li];
-                    for ( int smp = 0; smp < l.nSamples; ++smp, ++slot )
-                    {
-                        f3 wi, Li = F3( l.Lemit );
-                        float pdf = 1.0f, tMax;
-                        bool skip = false;
-                        if ( l.type == PT_LIGHT_POINT ) // src/lights.cpp:8-23
-                        {
-                            f3 toLight = F3( l.a ) - position;
-                            wi   = Normalize( toLight );
-                            tMax = Length( toLight );
-                            Li   = Li / ( tMax * tMax );
-                        }
-                        else if ( l.type == PT_LIGHT_DIRECTIONAL ) // src/lights.cpp:25-38
-                        {
-                            wi   = -F3( l.a );
-                            tMax = FLT_MAX;
-                        }
-                        else // src/lights.cpp:40-55 over src/shapes.cpp:11-30
-                        {
-                            // f( Rand(), Rand() ): g++ evaluates the arguments right to left, so the first
-                            // draw is u2 and the second u1
-                            float u2, u1;
-                            DrawPair( rng, pixel, sample, drawBase + 2u * ( l.drawOffset + smp ), &u2, &u1 );
-                            f3 sp, sn;
-                            if ( l.shapeType == PT_PRIM_TRIANGLE ) // src/shapes.cpp:104-115, src/sampling.cpp:63-67
-                            {
-                                float su0 = sqrtf( u1 );
-                                float bu = 1 - su0, bv = u2 * su0, bw = 1 - bu - bv;
-                                sp = F3( l.v0 ) * bu + F3( l.v1 ) * bv + F3( l.v2 ) * bw;
-                                sn = Normalize( F3( l.n0 ) * bu + F3( l.n1 ) * bv + F3( l.n2 ) * bw );
-                            }
-                            else // src/shapes.cpp:42-50
-                            {
-                                sn = UniformSampleSphere( u1, u2 );
-                                sp = F3( l.a ) + sn * l.radius;
-                            }
-                            pdf = l.invArea;
-                            f3 toLight = sp - position;
-                            if ( Length( toLight ) == 0 )
-                                pdf = 0;
-                            else
-                            {
-                                float r2 = Dot( toLight, toLight );
-                                f3 w     = Normalize( toLight );
-                                pdf *= r2 / AbsDot( sn, -w );
-                                if ( isinf( pdf ) ) pdf = 0.0f;
-                            }
-                            wi   = Normalize( sp - position );
-                            tMax = Length( sp - position );
-                            if ( static_cast< double >( tMax ) < 0.002 ) skip = true;
-                            if ( !( Dot( -wi, sn ) > 0 ) ) skip = true; // one-sided emitter
-                        }
-                        f3 est = F3( 0.0f, 0.0f, 0.0f );
-                        if ( pdf == 0 )
-                            skip = true;
-                        else
-                            est = ( ( F * Li ) * AbsDot( normal, wi ) ) / pdf; // path_tracer.cpp:87
-                        if ( IsZero( est ) ) skip = true;
-                        const size_t rec = static_cast< size_t >( slot ) * pb.capacity + p;
-                        pb.shDir[rec] = F4( wi, skip ? -1.0f : tMax );
-                        if ( !skip )
-                        {
-                            pb.shEst[rec] = F4( est, 0.0f );
-                            anyShadow     = true;
-                        }
-                    }
-                }
+                    lit         = true;
+                    sf.wo       = -d;
+                    sf.position = sf.position + sf.normal * kEpsilon; // path_tracer.cpp:122
 
-                // BRDF::Sample_F / Pdf (src/resource/material.cpp:20-32) and the throughput update
-                // (path_tracer.cpp:139-152)
-                float u2, u1;
-                DrawPair( rng, pixel, sample, drawBase + static_cast< uint32_t >( sv.drawsPerBounce ) - 2u, &u2, &u1 );
-                f3 local = CosineSampleHemisphere( u1, u2 );
-                f3 wi    = tangent * local.x + bitangent * local.y + normal * local.z;
-                bool sameHemisphere = Dot( wo, normal ) * Dot( wi, normal ) > 0;
-                float pdf = sameHemisphere ? AbsDot( wi, normal ) / kPi : 0.0f;
-                if ( !( pdf == 0.0f || IsZero( F ) ) )
-                {
-                    f3 Tn = T * ( ( F * AbsDot( wi, normal ) ) / pdf );
-                    if ( !IsZero( Tn ) && bounce + 1 < maxDepth )
-                    {
-                        alive          = true;
-                        pb.rayD[p]     = F4( wi, 0.0f );
-                        pb.thr[nxt][p] = F4( Tn, 0.0f );
-                    }
+                    const float4 m0 = sv.materials[2 * material], m1 = sv.materials[2 * material + 1];
+                    if ( bounce == 0 && Dot( sf.wo, sf.normal ) > 0 ) L = L + T * F3( m1 ); // path_tracer.cpp:125-128
+                    if ( bounce == 0 ) pb.rad[p] = F4( L, 0.0f );
+
+                    f3 Kd = F3( m0 ); // Material::GetAlbedo (src/resource/material.cpp:34-43)
+                    const int tex = __float_as_int( m0.w );
+                    if ( tex >= 0 ) Kd = Kd * TextureFetch( sv, tex, tu, tv );
+                    sf.F   = Kd / kPi; // BRDF::F (src/resource/material.cpp:15-18)
+                    pixel  = p % numPixels;
+                    sample = sampleBegin + p / numPixels;
                 }
-                if ( alive || anyShadow ) pb.rayO[p] = F4( position, 0.0f );
             }
         }
-        WaveAppend( alive, p, nextQueue, nextCount );
-        WaveAppend( anyShadow, p, pb.shadowQueue, shadowCount );
+        waveShaded += LanesSet( lit );
+
+        // LDirect / EstimateSingleDirect (path_tracer.cpp:74-104): one shadow record per light sample, queued for
+        // ConnectKernel (visibility) and summed by ResolveKernel.  The loop bounds are the same for every lane.
+        uint32_t slot = 0;
+        for ( uint32_t li = 0; li < sv.numLights; ++li )
+        {
+            const DevLight& l = sv.lights[li];
+            for ( int smp = 0; smp < l.nSamples; ++smp, ++slot )
+            {
+                bool skip = true;
+                const uint32_t rec = slot * static_cast< uint32_t >( pb.capacity ) + p;
+                if ( lit )
+                {
+                    skip = false;
+                    f3 wi, Li = F3( l.Lemit );
+                    float pdf = 1.0f, tMax;
+                    if ( l.type == PT_LIGHT_POINT ) // src/lights.cpp:8-23
+                    {
+                        f3 toLight = F3( l.a ) - sf.position;
+                        wi   = Normalize( toLight );
+                        tMax = Length( toLight );
+                        Li   = Li / ( tMax * tMax );
+                    }
+                    else if ( l.type == PT_LIGHT_DIRECTIONAL ) // src/lights.cpp:25-38
+                    {
+                        wi   = -F3( l.a );
+                        tMax = FLT_MAX;
+                    }
+                    else // src/lights.cpp:40-55 over src/shapes.cpp:11-30
+                    {
+                        // f( Rand(), Rand() ): g++ evaluates the arguments right to left, so the first
+                        // draw is u2 and the second u1
+                        float u2, u1;
+                        DrawPair( rng, pixel, sample, drawBase + 2u * ( l.drawOffset + smp ), &u2, &u1 );
+                        f3 sp, sn;
+                        if ( l.shapeType == PT_PRIM_TRIANGLE ) // src/shapes.cpp:104-115, src/sampling.cpp:63-67
+                        {
+                            float su0 = sqrtf( u1 );
+                            float bu = 1 - su0, bv = u2 * su0, bw = 1 - bu - bv;
+                            sp = F3( l.v0 ) * bu + F3( l.v1 ) * bv + F3( l.v2 ) * bw;
+                            sn = Normalize( F3( l.n0 ) * bu + F3( l.n1 ) * bv + F3( l.n2 ) * bw );
+                        }
+                        else // src/shapes.cpp:42-50
+                        {
+                            sn = UniformSampleSphere( u1, u2 );
+                            sp = F3( l.a ) + sn * l.radius;
+                        }
+                        pdf = l.invArea;
+                        f3 toLight = sp - sf.position;
+                        if ( Length( toLight ) == 0 )
+                            pdf = 0;
+                        else
+                        {
+                            float r2 = Dot( toLight, toLight );
+                            f3 w     = Normalize( toLight );
+                            pdf *= r2 / AbsDot( sn, -w );
+                            if ( isinf( pdf ) ) pdf = 0.0f;
+                        }
+                        wi   = Normalize( sp - sf.position );
+                        tMax = Length( sp - sf.position );
+                        if ( static_cast< double >( tMax ) < 0.002 ) skip = true;
+                        if ( !( Dot( -wi, sn ) > 0 ) ) skip = true; // one-sided emitter
+                    }
+                    f3 est = F3( 0.0f, 0.0f, 0.0f );
+                    if ( pdf == 0 )
+                        skip = true;
+                    else
+                        est = ( ( sf.F * Li ) * AbsDot( sf.normal, wi ) ) / pdf; // path_tracer.cpp:87
+                    if ( IsZero( est ) ) skip = true;
+                    pb.shDir[rec] = F4( wi, skip ? -1.0f : tMax );
+                    if ( !skip )
+                    {
+                        pb.shEst[rec] = F4( est, 0.0f );
+                        anyShadow     = true;
+                    }
+                }
+                SegmentAppend( !skip, rec, outShadowRays, nShadowRays );
+            }
+        }
+
+        // BRDF::Sample_F / Pdf (src/resource/material.cpp:20-32) and the throughput update (path_tracer.cpp:139-152)
+        if ( lit )
+        {
+            float u2, u1;
+            DrawPair( rng, pixel, sample, drawBase + static_cast< uint32_t >( sv.drawsPerBounce ) - 2u, &u2, &u1 );
+            f3 local = CosineSampleHemisphere( u1, u2 );
+            f3 wi    = sf.tangent * local.x + sf.bitangent * local.y + sf.normal * local.z;
+            bool sameHemisphere = Dot( sf.wo, sf.normal ) * Dot( wi, sf.normal ) > 0;
+            float pdf = sameHemisphere ? AbsDot( wi, sf.normal ) / kPi : 0.0f;
+            if ( !( pdf == 0.0f || IsZero( sf.F ) ) )
+            {
+                f3 Tn = T * ( ( sf.F * AbsDot( wi, sf.normal ) ) / pdf );
+                if ( !IsZero( Tn ) && bounce + 1 < maxDepth )
+                {
+                    alive          = true;
+                    pb.rayD[p]     = F4( wi, 0.0f );
+                    pb.thr[nxt][p] = F4( Tn, 0.0f );
+                }
+            }
+            if ( alive || anyShadow ) pb.rayO[p] = F4( sf.position, 0.0f );
+        }
+        SegmentAppend( alive, p, outNext, nNext );
+        SegmentAppend( anyShadow, p, outShadowPaths, nShadowPaths );
+        if constexpr ( !kSphereHits ) SegmentAppend( deferred, p, pb.sphereQueue + segment, nSpheres );
     }
-    FlushCounter( stats, ST_SHADED, shaded );
+    if ( LaneIndex() == 0 )
+    {
+        *UnitCount( pb, bounce, kCountNextPaths, unit )   = nNext;
+        *UnitCount( pb, bounce, kCountShadowPaths, unit ) = nShadowPaths;
+        *UnitCount( pb, bounce, kCountShadowRays, unit )  = nShadowRays;
+        if constexpr ( !kSphereHits ) *UnitCount( pb, bounce, kCountSphereHits, unit ) = nSpheres;
+    }
+    FlushWaveCounter( stats, ST_SHADED, waveShaded );
 }
 
-// Visibility of the shadow records of one path, then L += throughput * sum over lights of
-// ( sum over samples ) / nSamples (path_tracer.cpp:90-104, 133-134), in light order.
-__global__ __launch_bounds__( kBlock ) void ConnectKernel( SceneView sv, PathBuffers pb, int bounce, uint64_t* stats )
+// L += throughput * sum over lights of ( sum over the unoccluded samples ) / nSamples (path_tracer.cpp:90-104,
+// 133-134), in light and sample order, for every path that queued a shadow ray.
+__global__ __launch_bounds__( kBlock ) void ResolveKernel( SceneView sv, PathBuffers pb, int bounce )
 {
-    const uint32_t count = pb.counts[2 * bounce + 1];
+    const uint32_t unit = WaveIndex(); // one unit per wave
+    if ( unit >= pb.units ) return;
+    const uint32_t* items = pb.shadowPaths + unit * kUnitPaths;
+    const uint32_t limit  = *UnitCount( pb, bounce, kCountShadowPaths, unit );
     const int cur = bounce & 1;
-    Counters cnt;
-    for ( uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < count; i += gridDim.x * kBlock )
+    const uint32_t capacity = static_cast< uint32_t >( pb.capacity );
+    for ( uint32_t j = LaneIndex(); j < limit; j += 64u )
     {
-        const uint32_t p = pb.shadowQueue[i];
-        const f3 o = F3( pb.rayO[p] );
+        const uint32_t p = items[j];
         f3 Ldirect = F3( 0.0f, 0.0f, 0.0f );
-        int slot = 0;
+        uint32_t slot = 0;
         for ( uint32_t li = 0; li < sv.numLights; ++li )
         {
             const int nSamples = sv.lights[li].nSamples;
             f3 Ld = F3( 0.0f, 0.0f, 0.0f );
             for ( int smp = 0; smp < nSamples; ++smp, ++slot )
             {
-                const size_t rec = static_cast< size_t >( slot ) * pb.capacity + p;
-                const float4 dir = pb.shDir[rec];
-                if ( dir.w < 0.0f ) continue;
-                cnt.rays++;
-                if ( !TraceAny( sv, MakeSceneBuffers( sv ), o, F3( dir ), dir.w, cnt ) ) Ld = Ld + F3( pb.shEst[rec] );
+                const uint32_t rec = slot * capacity + p;
+                const float tMax   = reinterpret_cast< const float* >( pb.shDir )[4ull * rec + 3];
+                if ( tMax < 0.0f ) continue; // -1: no ray was cast, -2: occluded
+                Ld = Ld + F3( pb.shEst[rec] );
             }
             Ldirect = Ldirect + Ld / static_cast< float >( nSamples );
         }
@@ -798,10 +1019,6 @@ __global__ __launch_bounds__( kBlock ) void ConnectKernel( SceneView sv, PathBuf
         f3 L       = F3( pb.rad[p] );
         pb.rad[p]  = F4( L + T * Ldirect, 0.0f );
     }
-    FlushCounter( stats, ST_RAYS_SHADOW, cnt.rays );
-    FlushCounter( stats, ST_NODES_SHADOW, cnt.nodes );
-    FlushCounter( stats, ST_TRI_SHADOW, cnt.tris );
-    FlushCounter( stats, ST_SPH_SHADOW, cnt.spheres );
 }
 
 // totalColor += Li( sample ) in sample order (path_tracer.cpp:185-191); film.w counts the samples
@@ -911,31 +1128,48 @@ static int GridFor( const LaunchCfg& cfg, uint64_t work )
     return static_cast< int >( blocks );
 }
 
+// One unit per wave, four waves per block
+static dim3 UnitGrid( const PathBuffers& pb ) { return dim3( ( pb.units + kBlock / 64 - 1 ) / ( kBlock / 64 ) ); }
+
+void TraversalOccupancy( int* extendBlocksPerCu, int* connectBlocksPerCu )
+{
+    int e = 0, c = 0;
+    if ( hipOccupancyMaxActiveBlocksPerMultiprocessor( &e, ExtendKernel, kBlock, 0 ) != hipSuccess || e < 1 ) e = 4;
+    if ( hipOccupancyMaxActiveBlocksPerMultiprocessor( &c, ConnectKernel, kBlock, 0 ) != hipSuccess || c < 1 ) c = 4;
+    *extendBlocksPerCu  = e;
+    *connectBlocksPerCu = c;
+}
+
 void LaunchRaygen( const LaunchCfg& cfg, const CameraFrame& cam, const RngParams& rng, const PathBuffers& pb, uint32_t width,
                    uint32_t height, uint32_t sampleBegin, uint32_t numPaths )
 {
     hipLaunchKernelGGL( RaygenKernel, dim3( GridFor( cfg, numPaths ) ), dim3( kBlock ), 0, cfg.stream, cam, rng, pb, width, height, sampleBegin, numPaths );
 }
 
-void LaunchExtend( const LaunchCfg& cfg, const SceneView& sv, const PathBuffers& pb, const uint32_t* queue, const uint32_t* countPtr,
-                   uint32_t fixedCount, uint64_t* stats )
+void LaunchExtend( const LaunchCfg& cfg, const SceneView& sv, const PathBuffers& pb, int bounce, uint32_t numPaths, uint64_t* stats )
 {
-    const uint64_t work = countPtr ? pb.capacity : fixedCount;
-    hipLaunchKernelGGL( ExtendKernel, dim3( GridFor( cfg, work ) ), dim3( kBlock ), 0, cfg.stream, sv, pb, queue, countPtr, fixedCount, stats );
+    hipLaunchKernelGGL( ExtendKernel, dim3( cfg.extendBlocks ), dim3( kBlock ), 0, cfg.stream, sv, pb, bounce, numPaths, stats );
 }
 
 void LaunchShade( const LaunchCfg& cfg, const SceneView& sv, const RngParams& rng, const PathBuffers& pb, int bounce, int maxDepth,
-                  uint32_t width, uint32_t height, uint32_t sampleBegin, const uint32_t* queue, const uint32_t* countPtr,
-                  uint32_t fixedCount, uint64_t* stats )
+                  uint32_t width, uint32_t height, uint32_t sampleBegin, uint32_t numPaths, uint64_t* stats )
 {
-    const uint64_t work = countPtr ? pb.capacity : fixedCount;
-    hipLaunchKernelGGL( ShadeKernel, dim3( GridFor( cfg, work ) ), dim3( kBlock ), 0, cfg.stream, sv, rng, pb, bounce, maxDepth, width, height,
-                        sampleBegin, queue, countPtr, fixedCount, stats );
+    hipLaunchKernelGGL( ShadeKernel< false >, UnitGrid( pb ), dim3( kBlock ), 0, cfg.stream, sv, rng, pb, bounce, maxDepth, width, height,
+                        sampleBegin, numPaths, stats );
+    // paths whose closest hit is a sphere were deferred to their own queue
+    if ( sv.numSpheres != 0 )
+        hipLaunchKernelGGL( ShadeKernel< true >, UnitGrid( pb ), dim3( kBlock ), 0, cfg.stream, sv, rng, pb, bounce, maxDepth, width, height,
+                            sampleBegin, numPaths, stats );
 }
 
 void LaunchConnect( const LaunchCfg& cfg, const SceneView& sv, const PathBuffers& pb, int bounce, uint64_t* stats )
 {
-    hipLaunchKernelGGL( ConnectKernel, dim3( GridFor( cfg, pb.capacity ) ), dim3( kBlock ), 0, cfg.stream, sv, pb, bounce, stats );
+    hipLaunchKernelGGL( ConnectKernel, dim3( cfg.connectBlocks ), dim3( kBlock ), 0, cfg.stream, sv, pb, bounce, stats );
+}
+
+void LaunchResolve( const LaunchCfg& cfg, const SceneView& sv, const PathBuffers& pb, int bounce )
+{
+    hipLaunchKernelGGL( ResolveKernel, UnitGrid( pb ), dim3( kBlock ), 0, cfg.stream, sv, pb, bounce );
 }
 
 void LaunchFilm( const LaunchCfg& cfg, const PathBuffers& pb, float4* film, uint32_t numPixels, uint32_t samplesInPass )

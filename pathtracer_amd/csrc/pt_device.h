@@ -63,6 +63,7 @@ struct SceneView
     const float4* skybox; // 6 * w * h texels or nullptr
     uint32_t numNodes;
     uint32_t numPrims;
+    uint32_t numSpheres;
     uint32_t numLights;
     int32_t shadowSlots;     // sum of nSamples over all lights
     int32_t drawsPerBounce;  // 2 * (area light samples) + 2
@@ -95,12 +96,26 @@ struct PathBuffers
     float4* thr[2];    // throughput, double buffered per bounce
     float4* rad;       // accumulated radiance of the path
     float4* hit;       // t, u, v, prim (int bits; -1 = miss)
-    float4* shDir;     // [slot * capacity + path]: wi.xyz, tMax (negative = no ray)
+    float4* shDir;     // [slot * capacity + path]: wi.xyz, tMax (-1 = no ray, -2 = occluded)
     float4* shEst;     // [slot * capacity + path]: unoccluded contribution
-    uint32_t* queue[2];
-    uint32_t* shadowQueue;
-    uint32_t* counts;  // [bounce][2]: paths continuing into bounce + 1, paths with shadow rays
-    uint64_t capacity;
+    uint32_t* queue[2];     // path ids entering a bounce, double buffered
+    uint32_t* shadowPaths;  // path ids that cast at least one shadow ray this bounce
+    uint32_t* shadowRays;   // shadow record indices (slot * capacity + path) to test for occlusion, capacity * slots entries
+    uint32_t* sphereQueue;  // path ids whose closest hit is a sphere, shaded by their own kernel instance
+    uint32_t* counts;       // [bounce][kCountsPerBounce][unit] queue segment lengths
+    uint32_t* cursors;      // [bounce][2] next unit to hand out in ExtendKernel / ConnectKernel
+    uint64_t capacity;      // paths in flight; capacity * shadow slots < 2^32
+    uint32_t units;         // units of kUnitPaths consecutive path ids in this pass
+    uint32_t shadowSlots;   // shadow records per path, at least 1
+};
+
+// Paths per unit of work; every queue has one segment of this many entries (times shadowSlots for shadowRays) per unit
+constexpr uint32_t kUnitPaths = 256;
+
+// Queue length slots of one bounce in PathBuffers::counts
+enum
+{
+    kCountNextPaths, kCountShadowPaths, kCountShadowRays, kCountSphereHits, kCountsPerBounce
 };
 
 // Counter slots in the device statistics block
@@ -113,18 +128,21 @@ enum
 struct LaunchCfg
 {
     hipStream_t stream;
-    int blocks; // grid size of the grid-stride kernels
+    int blocks;        // grid size of the grid-stride kernels
+    int extendBlocks;  // resident blocks of ExtendKernel
+    int connectBlocks; // resident blocks of ConnectKernel
 };
 
 // --- launch wrappers (kernels.hip) ---------------------------------------------------------------------
 void LaunchRaygen( const LaunchCfg& cfg, const CameraFrame& cam, const RngParams& rng, const PathBuffers& pb,
                    uint32_t width, uint32_t height, uint32_t sampleBegin, uint32_t numPaths );
-void LaunchExtend( const LaunchCfg& cfg, const SceneView& sv, const PathBuffers& pb, const uint32_t* queue,
-                   const uint32_t* countPtr, uint32_t fixedCount, uint64_t* stats );
+// resident blocks per compute unit of the two traversal kernels (occupancy query)
+void TraversalOccupancy( int* extendBlocksPerCu, int* connectBlocksPerCu );
+void LaunchExtend( const LaunchCfg& cfg, const SceneView& sv, const PathBuffers& pb, int bounce, uint32_t numPaths, uint64_t* stats );
 void LaunchShade( const LaunchCfg& cfg, const SceneView& sv, const RngParams& rng, const PathBuffers& pb, int bounce,
-                  int maxDepth, uint32_t width, uint32_t height, uint32_t sampleBegin, const uint32_t* queue,
-                  const uint32_t* countPtr, uint32_t fixedCount, uint64_t* stats );
+                  int maxDepth, uint32_t width, uint32_t height, uint32_t sampleBegin, uint32_t numPaths, uint64_t* stats );
 void LaunchConnect( const LaunchCfg& cfg, const SceneView& sv, const PathBuffers& pb, int bounce, uint64_t* stats );
+void LaunchResolve( const LaunchCfg& cfg, const SceneView& sv, const PathBuffers& pb, int bounce );
 void LaunchFilm( const LaunchCfg& cfg, const PathBuffers& pb, float4* film, uint32_t numPixels, uint32_t samplesInPass );
 void LaunchTonemap( const LaunchCfg& cfg, const float4* film, float* linearOut, float* tonemappedOut, uint32_t numPixels,
                     float exposure, float gamma, uint32_t op );
