@@ -21,6 +21,7 @@ events on the stream the kernels run on; and `cpu_baseline`: the CPU restatement
 (oracle/pt_oracle.c, OpenMP) timed on this host over a bounded sample of the same frame.
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -111,7 +112,8 @@ def main():
 
     stats = dev.stats()
     counters = ["samples", "rays_closest", "rays_shadow", "nodes_closest", "nodes_shadow", "tri_tests_closest",
-                "tri_tests_shadow", "sphere_tests_closest", "sphere_tests_shadow", "shaded_hits"]
+                "tri_tests_shadow", "sphere_tests_closest", "sphere_tests_shadow", "shaded_hits", "node_steps_closest",
+                "node_steps_shadow"]
     mine = {c: getattr(stats, c) - getattr(warm, c) for c in counters}   # timed steps only
     if dist is not None:
         t = torch.tensor([mine[c] for c in counters], device=f"cuda:{local_rank}", dtype=torch.int64)
@@ -129,14 +131,30 @@ def main():
         bytes_shadow = 32 * mine["nodes_shadow"] + 48 * mine["tri_tests_shadow"] + 16 * mine["sphere_tests_shadow"] + 36 * mine["rays_shadow"]
         if ms["extend"] >= ms["connect"]:
             kernel, kbytes, kms, klaunch, krays = "ExtendKernel", bytes_closest, ms["extend"], launches["extend"], mine["rays_closest"]
+            knodes, ksteps = mine["nodes_closest"], mine["node_steps_closest"]
         else:
             kernel, kbytes, kms, klaunch, krays = "ConnectKernel", bytes_shadow, ms["connect"], launches["connect"], mine["rays_shadow"]
+            knodes, ksteps = mine["nodes_shadow"], mine["node_steps_shadow"]
         achieved = kbytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+        # bytes that left the L2 per launch of that kernel (reads corrected for gfx950, writes as counted), from the
+        # newest committed rocprofv3 --pmc summary of this same command (profiles/collect_pmc.sh); null without one
+        traffic, traffic_source = None, None
+        summaries = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
+        if summaries:
+            try:
+                entry = json.load(open(summaries[-1])).get(kernel, {})
+                if "fabric_read_bytes" in entry:
+                    traffic = round(entry["fabric_read_bytes"] + entry.get("fabric_write_bytes", 0.0))
+                    traffic_source = os.path.relpath(summaries[-1], ROOT)
+            except (OSError, ValueError):
+                pass
         roofline = {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                     "bytes_per_launch": round(kbytes / max(1, klaunch)), "avg_launch_ms": round(kms / max(1, klaunch), 4),
                     "launches": klaunch, "bytes_per_ray": round(kbytes / max(1, krays), 1),
-                    "grays_per_s_in_kernel": round(krays / (kms * 1e-3) / 1e9, 3) if kms > 0 else 0.0}
+                    "grays_per_s_in_kernel": round(krays / (kms * 1e-3) / 1e9, 3) if kms > 0 else 0.0,
+                    "nodes_per_ray": round(knodes / max(1, krays), 2),
+                    "lanes_per_node_step": round(knodes / max(1, ksteps), 2)}
 
         cpu = None
         if args.cpu_baseline_spp > 0 and world == 1:

@@ -239,6 +239,8 @@ typedef struct PtStats
     uint64_t sphere_tests_closest;
     uint64_t sphere_tests_shadow;
     uint64_t shaded_hits;
+    uint64_t node_steps_closest; /* wave-level node visits (one step serves up to 64 rays): SIMD lane  */
+    uint64_t node_steps_shadow;  /* utilisation of the traversal = nodes / (64 * node_steps)          */
     uint64_t launches[PT_K_COUNT];
     double   kernel_ms[PT_K_COUNT]; /* PT_RENDER_PROFILE only, summed over launches */
     double   render_ms;             /* host wall time of the pt_render calls, synchronised */

@@ -81,7 +81,7 @@ class PtStats(C.Structure):
         ("nodes_closest", C.c_uint64), ("nodes_shadow", C.c_uint64),
         ("tri_tests_closest", C.c_uint64), ("tri_tests_shadow", C.c_uint64),
         ("sphere_tests_closest", C.c_uint64), ("sphere_tests_shadow", C.c_uint64),
-        ("shaded_hits", C.c_uint64),
+        ("shaded_hits", C.c_uint64), ("node_steps_closest", C.c_uint64), ("node_steps_shadow", C.c_uint64),
         ("launches", C.c_uint64 * PT_K_COUNT), ("kernel_ms", C.c_double * PT_K_COUNT),
         ("render_ms", C.c_double),
     ]

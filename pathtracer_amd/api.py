@@ -10,7 +10,8 @@ import numpy as np
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libptamd.so")
+# PTAMD_LIB selects another build of the same library (kernel tuning experiments)
+LIB_PATH = os.environ.get("PTAMD_LIB") or os.path.join(_HERE, "libptamd.so")
 _LIB = None
 
 

@@ -707,6 +707,8 @@ int pt_readback( PtScene* s, uint32_t tonemap, float* rgb_linear, float* rgb_ton
         stats->sphere_tests_closest = dev[ST_SPH_CLOSEST];
         stats->sphere_tests_shadow  = dev[ST_SPH_SHADOW];
         stats->shaded_hits          = dev[ST_SHADED];
+        stats->node_steps_closest   = dev[ST_STEPS_CLOSEST];
+        stats->node_steps_shadow    = dev[ST_STEPS_SHADOW];
         std::memcpy( stats->launches, s->launches, sizeof( s->launches ) );
         std::memcpy( stats->kernel_ms, s->kernelMs, sizeof( s->kernelMs ) );
         stats->render_ms = s->renderMs;

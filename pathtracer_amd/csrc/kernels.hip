@@ -526,9 +526,18 @@ __device__ __forceinline__ void FlushWaveCounter( uint64_t* stats, int slot, uin
 //   traverse  otherwise: up to kTraverseBurst node visits for the traversing lanes
 // A phase also runs as soon as nothing else can make progress, so every lane terminates.  Per ray the sequence
 // of node visits and primitive tests is unchanged: a waiting lane does nothing, it never runs ahead.
-constexpr int kRefillLanes   = 16;
-constexpr int kLeafLanes     = 12;
-constexpr int kTraverseBurst = 6;
+#ifndef PT_REFILL_LANES
+#define PT_REFILL_LANES 16
+#endif
+#ifndef PT_LEAF_LANES
+#define PT_LEAF_LANES 12
+#endif
+#ifndef PT_TRAVERSE_BURST
+#define PT_TRAVERSE_BURST 6
+#endif
+constexpr int kRefillLanes   = PT_REFILL_LANES;
+constexpr int kLeafLanes     = PT_LEAF_LANES;
+constexpr int kTraverseBurst = PT_TRAVERSE_BURST;
 
 // Closest hits of the rays entering `bounce`: BVH::Intersect (src/bvh.cpp:230-268) under Scene::Intersect
 // (src/scene.cpp:370-373).
@@ -543,7 +552,7 @@ __global__ __launch_bounds__( kBlock ) void ExtendKernel( SceneView sv, PathBuff
     f3 o = F3( 0.0f, 0.0f, 0.0f ), d = o, inv = o;
     bool nx = false, ny = false, nz = false;
     HitRecord h{ FLT_MAX, 0.0f, 0.0f, -1 };
-    uint32_t waveRays = 0, waveNodes = 0, waveTris = 0, waveSpheres = 0; // whole-wave totals, wave-uniform
+    uint32_t waveRays = 0, waveNodes = 0, waveTris = 0, waveSpheres = 0, waveSteps = 0; // whole-wave totals, wave-uniform
 
     for ( ;; )
     {
@@ -613,6 +622,7 @@ __global__ __launch_bounds__( kBlock ) void ExtendKernel( SceneView sv, PathBuff
             const uint32_t active = LanesSet( go );
             if ( burst && 2 * active < started ) break;
             waveNodes += active;
+            waveSteps++;
             if ( go )
             {
                 const float4 a = Load16( sb.nodes, 32u * node ), b = Load16( sb.nodes, 32u * node + 16u );
@@ -632,6 +642,7 @@ __global__ __launch_bounds__( kBlock ) void ExtendKernel( SceneView sv, PathBuff
     FlushWaveCounter( stats, ST_NODES_CLOSEST, waveNodes );
     FlushWaveCounter( stats, ST_TRI_CLOSEST, waveTris );
     FlushWaveCounter( stats, ST_SPH_CLOSEST, waveSpheres );
+    FlushWaveCounter( stats, ST_STEPS_CLOSEST, waveSteps );
 }
 
 // Visibility of the queued shadow rays: BVH::Occluded (src/bvh.cpp:270-310) under Scene::Occluded
@@ -647,7 +658,7 @@ __global__ __launch_bounds__( kBlock ) void ConnectKernel( SceneView sv, PathBuf
     f3 o = F3( 0.0f, 0.0f, 0.0f ), d = o, inv = o;
     float tMax = 0.0f;
     bool nx = false, ny = false, nz = false, occluded = false;
-    uint32_t waveRays = 0, waveNodes = 0, waveTris = 0, waveSpheres = 0; // whole-wave totals, wave-uniform
+    uint32_t waveRays = 0, waveNodes = 0, waveTris = 0, waveSpheres = 0, waveSteps = 0; // whole-wave totals, wave-uniform
 
     for ( ;; )
     {
@@ -723,6 +734,7 @@ __global__ __launch_bounds__( kBlock ) void ConnectKernel( SceneView sv, PathBuf
             const uint32_t active = LanesSet( go );
             if ( burst && 2 * active < started ) break;
             waveNodes += active;
+            waveSteps++;
             if ( go )
             {
                 const float4 a = Load16( sb.nodes, 32u * node ), b = Load16( sb.nodes, 32u * node + 16u );
@@ -742,6 +754,7 @@ __global__ __launch_bounds__( kBlock ) void ConnectKernel( SceneView sv, PathBuf
     FlushWaveCounter( stats, ST_NODES_SHADOW, waveNodes );
     FlushWaveCounter( stats, ST_TRI_SHADOW, waveTris );
     FlushWaveCounter( stats, ST_SPH_SHADOW, waveSpheres );
+    FlushWaveCounter( stats, ST_STEPS_SHADOW, waveSteps );
 }
 
 // ------------------------------------------------------------------------------------------------ shading

@@ -122,7 +122,7 @@ enum
 enum
 {
     ST_RAYS_CLOSEST, ST_RAYS_SHADOW, ST_NODES_CLOSEST, ST_NODES_SHADOW, ST_TRI_CLOSEST, ST_TRI_SHADOW,
-    ST_SPH_CLOSEST, ST_SPH_SHADOW, ST_SHADED, ST_COUNT
+    ST_SPH_CLOSEST, ST_SPH_SHADOW, ST_SHADED, ST_STEPS_CLOSEST, ST_STEPS_SHADOW, ST_COUNT
 };
 
 struct LaunchCfg

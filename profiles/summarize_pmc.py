@@ -1,13 +1,55 @@
-"""Sums rocprofv3 --pmc counter CSVs per kernel and counter: python summarize_pmc.py <dir with pass subdirs>."""
-import csv, glob, os, sys
+"""Per kernel: dispatches and per-dispatch means of the rocprofv3 --pmc counters found under <dir>/<pass>/,
+plus the kernel-trace duration statistics when <dir>/trace is there.  Writes <dir>/pmc_summary.json and prints
+a table.  usage: python summarize_pmc.py <dir>
+
+Derived per-dispatch figures: fabric_read_bytes = FETCH_SIZE (KiB) * 1024 * 2 -- on gfx950 FETCH_SIZE tallies
+the memory-side read requests at half their size; fabric_write_bytes = WRITE_SIZE (KiB) * 1024.  Both count
+requests that leave the L2, including those the Infinity Cache serves."""
+import csv, glob, json, os, sys
 from collections import defaultdict
+
 root = sys.argv[1]
-tot = defaultdict(lambda: defaultdict(float)); calls = defaultdict(set)
+
+
+def short(name):
+    name = name.split("(")[0].replace("ptd::", "").replace("void ", "")
+    return name.strip()
+
+
+tot = defaultdict(lambda: defaultdict(float))
+disp = defaultdict(lambda: defaultdict(set))
 for f in glob.glob(os.path.join(root, "*", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0].replace("ptd::", "")
-        tot[k][r["Counter_Name"]] += float(r["Counter_Value"]); calls[k].add((f, r["Dispatch_Id"]))
+        k, c = short(r["Kernel_Name"]), r["Counter_Name"]
+        tot[k][c] += float(r["Counter_Value"])
+        disp[k][c].add(r["Dispatch_Id"])
+
+out = {}
 for k in sorted(tot):
-    print(f"{k}  dispatches={len(calls[k])//max(1,len(set(f for f,_ in calls[k])))}")
-    for c in sorted(tot[k]):
-        print(f"    {c:36s} {tot[k][c]:.6g}")
+    per = {c: tot[k][c] / max(1, len(disp[k][c])) for c in tot[k]}
+    n = max(len(v) for v in disp[k].values())
+    d = {"dispatches": n, "per_dispatch": per}
+    if "FETCH_SIZE" in per:
+        d["fabric_read_bytes"] = per["FETCH_SIZE"] * 1024 * 2
+    if "WRITE_SIZE" in per:
+        d["fabric_write_bytes"] = per["WRITE_SIZE"] * 1024
+    if "TCP_TOTAL_CACHE_ACCESSES_sum" in per and per["TCP_TOTAL_CACHE_ACCESSES_sum"] > 0:
+        d["l1_hit_rate"] = 1 - per.get("TCP_TCC_READ_REQ_sum", 0) / per["TCP_TOTAL_CACHE_ACCESSES_sum"]
+    if "TCC_REQ_sum" in per and per["TCC_REQ_sum"] > 0:
+        d["l2_hit_rate"] = 1 - per.get("TCC_MISS_sum", 0) / per["TCC_REQ_sum"]
+    if "SQ_WAVE_CYCLES" in per and per["SQ_WAVE_CYCLES"] > 0:
+        d["wave_time_waiting_on_memory"] = per.get("SQ_WAIT_ANY", 0) / per["SQ_WAVE_CYCLES"]
+        d["wave_time_issue_stalled"] = per.get("SQ_WAIT_INST_ANY", 0) / per["SQ_WAVE_CYCLES"]
+    out[k] = d
+
+for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_stats.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = short(r["Name"])
+        out.setdefault(k, {})["trace"] = {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]), "total_ns": float(r["TotalDurationNs"]),
+                                          "percent": float(r["Percentage"])}
+
+json.dump(out, open(os.path.join(root, "pmc_summary.json"), "w"), indent=1, sort_keys=True)
+for k, d in out.items():
+    print(k, {x: (round(v, 4) if isinstance(v, float) else v) for x, v in d.items() if x != "per_dispatch"})
+    for c, v in sorted(d.get("per_dispatch", {}).items()):
+        print(f"    {c:36s} {v:.6g}")
