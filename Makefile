@@ -21,10 +21,11 @@ HIP_SRC  := $(wildcard pathtracer_amd/csrc/*.hip)
 HIP_HDR  := $(wildcard pathtracer_amd/csrc/*.h) $(wildcard pathtracer_amd/csrc/*.hpp) $(wildcard include/*.h)
 HIP_FLAGS := --offload-arch=gfx950 -std=c++17 -O3 -fPIC -ffp-contract=off -fno-fast-math -Wall $(INC)
 
-all: host device oracle ref
+all: host device cli oracle ref
 
 host: pathtracer_amd/libpthost.so
 device: pathtracer_amd/libptamd.so
+cli: pathtracer_amd/pathTracer
 oracle: oracle/libptoracle.so
 
 pathtracer_amd/libpthost.so: $(HOST_LIB_SRC) $(HOST_HDR)
@@ -34,7 +35,7 @@ pathtracer_amd/libptamd.so: $(HIP_SRC) $(HIP_HDR)
 	$(HIPCC) $(HIP_FLAGS) -shared -o $@ $(HIP_SRC)
 
 pathtracer_amd/pathTracer: pathtracer_amd/host/main.cpp pathtracer_amd/libpthost.so pathtracer_amd/libptamd.so
-	$(CXX) $(HOST_FLAGS) -o $@ pathtracer_amd/host/main.cpp -Lpathtracer_amd -lpthost -lptamd -Wl,-rpath,'$$ORIGIN'
+	$(CXX) $(HOST_FLAGS) -o $@ pathtracer_amd/host/main.cpp -Lpathtracer_amd -lpthost -lptamd -L/opt/rocm/lib -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,/opt/rocm/lib -Wl,--allow-shlib-undefined
 
 oracle/libptoracle.so: oracle/pt_oracle.c oracle/pt_oracle.h include/pt_api.h
 	$(CC) -std=c11 -O2 -fPIC -fopenmp -ffp-contract=off -fno-fast-math -Wall $(INC) -shared -o $@ oracle/pt_oracle.c -lm
@@ -46,4 +47,4 @@ clean:
 	rm -f pathtracer_amd/libpthost.so pathtracer_amd/libptamd.so pathtracer_amd/pathTracer oracle/libptoracle.so
 	rm -rf oracle/_ref
 
-.PHONY: all host device oracle ref clean
+.PHONY: all host device cli oracle ref clean

@@ -8,6 +8,8 @@ import pytest
 from pathtracer_amd import abi, host
 from test_oracle_vs_reference import shape_boxes
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 
 @pytest.mark.parametrize("name", ["cornell", "mixed"])
 @pytest.mark.parametrize("method,tag", [(abi.PTH_SPLIT_SAH, "sah"), (abi.PTH_SPLIT_MIDDLE, "middle"), (abi.PTH_SPLIT_EQUAL_COUNTS, "equal")])
@@ -158,3 +160,25 @@ def test_image_writer_quantises_like_the_reference(tmp_path):
     assert np.array_equal(raw[:, 1:].reshape(2, 2, 3), want)
     with pytest.raises(host.HostError):
         host.write_image(str(tmp_path / "o.xyz"), rgb)
+
+
+def test_command_line_host_usage_and_failures(tmp_path):
+    """pathTracer keeps the reference's command line (src/main.cpp:13-29): one positional scene file, a usage
+    line otherwise, and exit status 0 even when the scene cannot be loaded.  Rendering needs a GPU; without
+    one the program says so instead of falling back to anything."""
+    import subprocess
+    exe = os.path.join(ROOT, "pathtracer_amd", "pathTracer")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", ROOT, "cli"], check=True, capture_output=True)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.strip() == "Usage: pathTracer SCENE_FILE"
+    r = subprocess.run([exe, "a.json", "b.json"], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.strip() == "Usage: pathTracer SCENE_FILE"
+    r = subprocess.run([exe, str(tmp_path / "missing.json")], capture_output=True, text=True)
+    assert r.returncode == 0 and "Could not load scene file" in r.stdout
+    r = subprocess.run([exe, "--generate", "knot", "--triangles", "2000", "--width", "32", "--height", "32", "--spp", "1",
+                        "--output", str(tmp_path / "k.png")], capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode == 0 and "Number of shapes: 2000" in r.stdout and "\tTriangles: 2000" in r.stdout
+    import torch
+    if not torch.cuda.is_available():
+        assert "Could not upload the scene" in r.stdout and not (tmp_path / "k.png").exists()
