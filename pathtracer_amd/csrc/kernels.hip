@@ -527,7 +527,7 @@ __device__ __forceinline__ void FlushWaveCounter( uint64_t* stats, int slot, uin
 // A phase also runs as soon as nothing else can make progress, so every lane terminates.  Per ray the sequence
 // of node visits and primitive tests is unchanged: a waiting lane does nothing, it never runs ahead.
 #ifndef PT_REFILL_LANES
-#define PT_REFILL_LANES 16
+#define PT_REFILL_LANES 32
 #endif
 #ifndef PT_LEAF_LANES
 #define PT_LEAF_LANES 12
@@ -535,13 +535,19 @@ __device__ __forceinline__ void FlushWaveCounter( uint64_t* stats, int slot, uin
 #ifndef PT_TRAVERSE_BURST
 #define PT_TRAVERSE_BURST 6
 #endif
+// occupancy target of ExtendKernel in waves per SIMD: 7 (72 VGPRs, a few spilled around the leaf phase) measured
+// 7 % faster than the compiler's own choice of 6 (80 VGPRs), 8 (64 VGPRs, spills in the node loop) 6 % slower
+#ifndef PT_EXTEND_WAVES
+#define PT_EXTEND_WAVES 7
+#endif
+#define PT_EXTEND_OCCUPANCY __attribute__( ( amdgpu_waves_per_eu( PT_EXTEND_WAVES, PT_EXTEND_WAVES ) ) )
 constexpr int kRefillLanes   = PT_REFILL_LANES;
 constexpr int kLeafLanes     = PT_LEAF_LANES;
 constexpr int kTraverseBurst = PT_TRAVERSE_BURST;
 
 // Closest hits of the rays entering `bounce`: BVH::Intersect (src/bvh.cpp:230-268) under Scene::Intersect
 // (src/scene.cpp:370-373).
-__global__ __launch_bounds__( kBlock ) void ExtendKernel( SceneView sv, PathBuffers pb, int bounce, uint32_t numPaths, uint64_t* stats )
+__global__ __launch_bounds__( kBlock ) PT_EXTEND_OCCUPANCY void ExtendKernel( SceneView sv, PathBuffers pb, int bounce, uint32_t numPaths, uint64_t* stats )
 {
     UnitStream stream{ pb.cursors + 2 * bounce, bounce == 0 ? nullptr : UnitCount( pb, bounce - 1, kCountNextPaths, 0 ), pb.units, kUnitPaths, numPaths };
     const uint32_t* items = bounce == 0 ? nullptr : pb.queue[bounce & 1];
