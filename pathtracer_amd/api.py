@@ -3,7 +3,9 @@
 There is no CPU fallback: if the library is missing or no GPU is visible, every entry point raises.
 """
 import ctypes as C
+import importlib.util
 import os
+import sys
 
 import numpy as np
 
@@ -21,12 +23,31 @@ class PtError(RuntimeError):
         self.code = code
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.  PyTorch's wheel carries its own libamdhip64.so.7 and libptamd.so asks for the
+    same soname, so whichever is loaded first serves both.  Device pointers are handed to torch
+    (path_tracer.film_tensor) and torch cannot start on the system copy once that is loaded, so when PyTorch is
+    installed but not imported yet its copy is loaded first.  Without PyTorch the system runtime is used."""
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.origin:
+        return
+    bundled = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(bundled):
+        C.CDLL(bundled, mode=C.RTLD_GLOBAL)
+
+
 def lib():
     global _LIB
     if _LIB is None:
         if not os.path.exists(LIB_PATH):
             raise PtError(abi.PT_ERR_DEVICE, f"{LIB_PATH} is missing: build it with `make device` "
                                              f"(or __graft_entry__.build()); there is no CPU fallback")
+        _share_hip_runtime_with_torch()
         L = C.CDLL(LIB_PATH)
         L.pt_last_error.restype = C.c_char_p
         L.pt_upload_scene.argtypes = [C.POINTER(abi.PtSceneDesc), C.POINTER(C.c_void_p)]

@@ -190,3 +190,34 @@ def test_invalid_scenes_are_rejected(scenes):
     with pytest.raises(api.PtError) as e:
         api.DeviceScene(d)
     assert e.value.code == abi.PT_ERR_INVALID_ARG
+
+
+def test_film_tensor_and_single_rank_rccl_reduce(device_scenes):
+    """The float4 film (sum r, g, b, sample count) is shared with torch without a copy and goes through one
+    RCCL reduce; with one rank the reduce must leave it unchanged."""
+    import os
+    import socket
+    import torch
+    import torch.distributed as dist
+    from pathtracer_amd import path_tracer
+
+    _, dev, _ = device_scenes["cornell"]
+    dev.render(4, seed=2)
+    lin, _, _ = dev.readback(abi.PT_TONEMAP_NONE, tonemapped=False)
+    film = path_tracer.film_tensor(dev, 0)
+    assert film.is_cuda and film.numel() == 48 * 48 * 4
+    host_film = film.cpu().numpy().reshape(48, 48, 4)
+    assert (host_film[..., 3] == 4).all()
+    assert_bits_equal(host_film[..., :3] / np.float32(4), lin, "film / count")
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        path_tracer.reduce_film(dev, 0, dist)
+        after = path_tracer.film_tensor(dev, 0).cpu().numpy().reshape(48, 48, 4)
+        assert_bits_equal(after, host_film, "film after a one-rank reduce")
+    finally:
+        dist.destroy_process_group()
