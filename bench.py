@@ -44,7 +44,8 @@ def parse():
     p.add_argument("--triangles", type=int, default=262267)
     p.add_argument("--texture-size", type=int, default=1024)
     p.add_argument("--seed", type=int, default=0)
-    p.add_argument("--cpu-baseline-spp", type=int, default=32, help="samples per pixel the CPU baseline renders (0 = skip)")
+    p.add_argument("--cpu-baseline-spp", type=int, default=64, help="most samples per pixel the CPU baseline renders (0 = skip)")
+    p.add_argument("--cpu-baseline-seconds", type=float, default=20.0, help="CPU time the baseline sample is sized for")
     p.add_argument("--save-image", default="", help="write the tonemapped frame of rank 0 to this file")
     return p.parse_args()
 
@@ -156,19 +157,44 @@ def main():
                     "nodes_per_ray": round(knodes / max(1, krays), 2),
                     "lanes_per_node_step": round(knodes / max(1, ksteps), 2)}
 
+        # what a plain device-to-device copy reaches on this GPU (read + write bytes), beside the nominal peak
+        if world == 1:
+            n = 1 << 30
+            src = torch.empty(n, dtype=torch.uint8, device=f"cuda:{local_rank}").fill_(1)
+            dst = torch.empty_like(src)
+            dst.copy_(src)
+            torch.cuda.synchronize(local_rank)
+            t1 = time.perf_counter()
+            for _ in range(10):
+                dst.copy_(src)
+            torch.cuda.synchronize(local_rank)
+            roofline["copy_measured_gbs"] = round(10 * 2 * n / (time.perf_counter() - t1) / 1e9, 1)
+            del src, dst
+
+        # CPU baseline beside the GPU number, rank 0 at N = 1 only: the reference's own compiled Li / BVH / shape code
+        # (oracle/_ref/libptref.so, built from /root/reference in the build container) when that library is here,
+        # else this repository's C restatement; on a bounded sample of the same frame sized for ~20 s of CPU work
         cpu = None
         if args.cpu_baseline_spp > 0 and world == 1:
-            from oracle import checker
-            orc = checker.OracleScene(desc)
+            from oracle import checker, ref
+            threads = checker.max_threads()
+            if ref.available():
+                cpu_scene, kind, what = ref.RefScene(desc), "reference", "the reference's sources (oracle/Makefile.ref) under oracle/ref_harness.cpp, OpenMP"
+            else:
+                cpu_scene, kind, what = checker.OracleScene(desc), "port", "oracle/pt_oracle.c with OpenMP"
             t1 = time.perf_counter()
-            _, ostats = orc.li_image(spp_total, 0, args.cpu_baseline_spp, seed=args.seed)
+            _, probe = cpu_scene.li_image(spp_total, 0, 1, seed=args.seed)
+            probe_s = time.perf_counter() - t1
+            n_spp = max(1, min(args.cpu_baseline_spp, int(args.cpu_baseline_seconds / max(probe_s, 1e-3))))
+            t1 = time.perf_counter()
+            _, cstats = cpu_scene.li_image(spp_total, 1, 1 + n_spp, seed=args.seed)
             cpu_s = time.perf_counter() - t1
-            cpu_rays = ostats["rays_closest"] + ostats["rays_shadow"]
-            cpu = {"value": round(cpu_rays / cpu_s / 1e6, 3), "unit": "Mrays/s", "cores": checker.max_threads(), "kind": "port",
-                   "msamples_per_s": round(ostats["samples"] / cpu_s / 1e6, 4), "seconds": round(cpu_s, 2),
-                   "sample": f"samples 0..{args.cpu_baseline_spp - 1} of every pixel of the same {args.width}x{args.height} frame "
-                             f"({ostats['samples']} pixel samples, {cpu_rays} rays incl. zero-contribution shadow rays), "
-                             f"oracle/pt_oracle.c with OpenMP"}
+            cpu_rays = cstats["rays_closest"] + cstats["rays_shadow"]
+            cpu_samples = args.width * args.height * n_spp
+            cpu = {"value": round(cpu_rays / cpu_s / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": kind,
+                   "msamples_per_s": round(cpu_samples / cpu_s / 1e6, 4), "seconds": round(cpu_s, 2),
+                   "sample": f"samples 1..{n_spp} of every pixel of the same {args.width}x{args.height} frame "
+                             f"({cpu_samples} pixel samples, {cpu_rays} rays incl. zero-contribution shadow rays), {what}"}
 
         if args.save_image:
             _, tm, _ = dev.readback(abi.PT_TONEMAP_UNCHARTED2, linear=False)

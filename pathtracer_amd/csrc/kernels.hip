@@ -541,6 +541,11 @@ __device__ __forceinline__ void FlushWaveCounter( uint64_t* stats, int slot, uin
 #define PT_EXTEND_WAVES 7
 #endif
 #define PT_EXTEND_OCCUPANCY __attribute__( ( amdgpu_waves_per_eu( PT_EXTEND_WAVES, PT_EXTEND_WAVES ) ) )
+#ifdef PT_CONNECT_WAVES
+#define PT_CONNECT_OCCUPANCY __attribute__( ( amdgpu_waves_per_eu( PT_CONNECT_WAVES, PT_CONNECT_WAVES ) ) )
+#else
+#define PT_CONNECT_OCCUPANCY
+#endif
 constexpr int kRefillLanes   = PT_REFILL_LANES;
 constexpr int kLeafLanes     = PT_LEAF_LANES;
 constexpr int kTraverseBurst = PT_TRAVERSE_BURST;
@@ -654,7 +659,7 @@ __global__ __launch_bounds__( kBlock ) PT_EXTEND_OCCUPANCY void ExtendKernel( Sc
 // Visibility of the queued shadow rays: BVH::Occluded (src/bvh.cpp:270-310) under Scene::Occluded
 // (src/scene.cpp:381-384), same scheduling as ExtendKernel.  One work item per shadow record; an occluded
 // record gets the distance -2 written back, so that ResolveKernel leaves it out of the sum.
-__global__ __launch_bounds__( kBlock ) void ConnectKernel( SceneView sv, PathBuffers pb, int bounce, uint64_t* stats )
+__global__ __launch_bounds__( kBlock ) PT_CONNECT_OCCUPANCY void ConnectKernel( SceneView sv, PathBuffers pb, int bounce, uint64_t* stats )
 {
     UnitStream stream{ pb.cursors + 2 * bounce + 1, UnitCount( pb, bounce, kCountShadowRays, 0 ), pb.units, kUnitPaths * pb.shadowSlots, 0u };
     const uint32_t end      = sv.numNodes;

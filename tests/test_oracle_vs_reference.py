@@ -109,3 +109,25 @@ def test_camera_and_sphere_transform_match_glm(scenes):
     view, up, right = host.camera_vectors(np.radians([0.0, 10.0, 0.0]).astype(np.float32))
     assert_bits_equal(view, small.camera["view_dir"], "view")
     assert_bits_equal(right, small.camera["right_dir"], "right")
+
+
+def test_benchmark_scene_bit_identical_to_reference_li():
+    """The benchmark's scene (262,267 triangles, 24 textures, directional light, depth 5) through the reference's
+    own Li / BVH::Intersect / Triangle::Intersect / Texture::GetPixel, against the checker: every pixel equal."""
+    with host.HostScene.atrium(seed=1, triangles=262267, texture_size=1024) as hs:
+        hs.set_image(240, 135, 240 / 135)
+        desc = hs.desc()
+        rs, orc = ref.RefScene(desc), checker.OracleScene(desc)
+        want, rstats = rs.li_image(2, seed=5)
+        got, ostats = orc.li_image(2, seed=5)
+        assert_bits_equal(got, want, "atrium radiance sums")
+        assert want.max() > 0
+        assert ostats["rays_closest"] == rstats["rays_closest"] and ostats["rays_shadow"] == rstats["rays_shadow"]
+        rng = np.random.default_rng(3)
+        o = np.array([[-9.0, 2.0, 0.0]], np.float32) + rng.uniform(-1, 1, (20000, 3)).astype(np.float32)
+        d = rng.normal(size=(20000, 3)).astype(np.float32)
+        a, b = rs.intersect(o, d), orc.intersect(o, d)
+        assert np.array_equal(a["prim"], b["prim"]) and (a["prim"] >= 0).mean() > 0.5
+        assert_bits_equal(a["t"], b["t"], "t")
+        assert np.array_equal(a["nodes"], b["nodes"]) and np.array_equal(a["prim_tests"], b["prim_tests"])
+        rs.close()
