@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -90,6 +91,7 @@ struct PtScene
     hipStream_t stream = nullptr;
     int gridBlocks = 2048;
     int extendBlocks = 1024, connectBlocks = 1024; // resident grids of the traversal kernels
+    uint32_t topNodes = 0;                          // nodes at the front of the device array in breadth-first order
 
     // scene
     DeviceBuffer nodes, prims, triShade, spheres, materials, textures, texels, lights, skybox;
@@ -232,17 +234,50 @@ int Upload( PtScene* s, const PtSceneDesc* d, const std::vector< uint32_t >& esc
     const uint32_t N = static_cast< uint32_t >( d->num_nodes );
     const uint64_t P = d->num_prims;
 
+    // Device order of the nodes: the top of the tree in breadth-first order (contiguous, so the nodes every ray
+    // visits share few cache lines), everything below in the reference's pre-order.  The traversal follows stored
+    // links, so the visit sequence is the reference's whatever the order in memory.
+    uint32_t top = kTopNodes;
+    if ( const char* env = std::getenv( "PT_TOP_NODES" ) ) top = static_cast< uint32_t >( std::strtoul( env, nullptr, 10 ) );
+    if ( top > N ) top = N;
+    std::vector< uint32_t > place( N + 1, 0xFFFFFFFFu ); // reference index -> device index
+    {
+        std::vector< uint32_t > bfs;
+        bfs.reserve( top );
+        if ( top > 0 ) bfs.push_back( 0 );
+        for ( size_t head = 0; head < bfs.size() && bfs.size() < top; ++head )
+        {
+            const PtBvhNode& n = d->nodes[bfs[head]];
+            if ( n.num_shapes > 0 ) continue;
+            if ( bfs.size() + 2 > top ) break; // siblings stay together
+            bfs.push_back( bfs[head] + 1 );
+            bfs.push_back( static_cast< uint32_t >( n.offset ) );
+        }
+        uint32_t next = 0;
+        for ( uint32_t i : bfs ) place[i] = next++;
+        for ( uint32_t i = 0; i < N; ++i )
+            if ( place[i] == 0xFFFFFFFFu ) place[i] = next++;
+        place[N] = N; // the end of the traversal
+        s->topNodes = static_cast< uint32_t >( bfs.size() );
+    }
+
     std::vector< float > nodes( 8ull * N );
     for ( uint32_t i = 0; i < N; ++i )
     {
         const PtBvhNode& n = d->nodes[i];
-        float* o = &nodes[8ull * i];
+        float* o = &nodes[8ull * place[i]];
         o[0] = n.aabb_min[0]; o[1] = n.aabb_min[1]; o[2] = n.aabb_min[2];
         o[3] = n.aabb_max[0]; o[4] = n.aabb_max[1]; o[5] = n.aabb_max[2];
-        uint32_t leaf = kInnerNode;
-        if ( n.num_shapes > 0 ) leaf = static_cast< uint32_t >( n.offset ) | ( static_cast< uint32_t >( n.num_shapes - 1 ) << 28 );
-        std::memcpy( &o[6], &escape[i], 4 );
-        std::memcpy( &o[7], &leaf, 4 );
+        // link word: where to go after this node's subtree, top bit set for a leaf; second word: the leaf's
+        // primitives, or the first child of an inner node
+        uint32_t link = place[escape[i]], word = place[i + 1 <= N ? i + 1 : N];
+        if ( n.num_shapes > 0 )
+        {
+            link |= kLeafFlag;
+            word = static_cast< uint32_t >( n.offset ) | ( static_cast< uint32_t >( n.num_shapes - 1 ) << 28 );
+        }
+        std::memcpy( &o[6], &link, 4 );
+        std::memcpy( &o[7], &word, 4 );
     }
     HIP_TRY( s->nodes.Upload( nodes.data(), nodes.size() * 4 ) );
 
@@ -375,6 +410,7 @@ int Upload( PtScene* s, const PtSceneDesc* d, const std::vector< uint32_t >& esc
     v.lights        = s->lights.As< DevLight >();
     v.skybox        = s->skybox.As< float4 >();
     v.numNodes      = N;
+    v.numTopNodes   = s->topNodes;
     v.numPrims      = static_cast< uint32_t >( P );
     v.numSpheres    = static_cast< uint32_t >( d->num_spheres );
     v.numLights     = static_cast< uint32_t >( d->num_lights );
@@ -652,7 +688,7 @@ int pt_render( PtScene* s, const PtRenderParams* p )
             }
         }
         span = timer.Begin( PT_K_FILM );
-        LaunchFilm( cfg, pb, s->film.As< float4 >(), static_cast< uint32_t >( pixels ), inPass );
+        LaunchFilm( cfg, pb, s->film.As< float4 >(), static_cast< uint32_t >( s->width ), static_cast< uint32_t >( s->height ), inPass );
         timer.End( span );
         HIP_TRY( hipGetLastError() );
         s->samples += numPaths;

@@ -15,11 +15,12 @@
 // comparisons instead of min/max in the slab test, so that hit primitives and distances equal the CPU's
 // bit for bit.
 //
-// Traversal: the node array is in depth-first pre-order with the first child at index + 1, and the
+// Traversal: the reference's node array is in depth-first pre-order with the first child at index + 1, and the
 // reference always descends into the first child first.  For that fixed order the node to visit after a
-// subtree is known statically, so every node carries an escape index (the pre-order successor of its
-// subtree) and the traversal needs no stack: hit inner -> index + 1, miss or leaf done -> escape.  The
-// visit sequence is exactly the reference's stack sequence, with no per-lane stack in LDS or scratch.
+// subtree is known statically (the pre-order successor of the subtree), so every device node carries it as a
+// link, next to the index of its first child, and the traversal needs no stack: hit inner -> first child,
+// miss or leaf done -> link.  The visit sequence is exactly the reference's stack sequence, with no per-lane
+// stack in LDS or scratch, whatever order the nodes have in device memory.
 #include "pt_device.h"
 #include "pt_api.h"
 #include "pt_sincosf.h"
@@ -222,14 +223,14 @@ __device__ __forceinline__ HitRecord TraceClosest( const SceneView& sv, const Sc
     {
         const float4 a = Load16( sb.nodes, 32u * node ), b = Load16( sb.nodes, 32u * node + 16u );
         cnt.nodes++;
-        const uint32_t escape = __float_as_uint( b.z ), leaf = __float_as_uint( b.w );
+        const uint32_t link = __float_as_uint( b.z ), leaf = __float_as_uint( b.w );
         const bool boxHit = RayBox( o, inv, nx, ny, nz, a, b, h.t );
-        if ( boxHit && leaf == kInnerNode )
+        if ( boxHit && !( link & kLeafFlag ) )
         {
-            node = node + 1;
+            node = leaf; // first child
             continue;
         }
-        node = escape;
+        node = link & ~kLeafFlag;
         if ( !boxHit ) continue;
         const uint32_t first = leaf & kLeafFirstMask, count = ( leaf >> 28 ) + 1;
         for ( uint32_t k = 0; k < count; ++k )
@@ -254,14 +255,14 @@ __device__ __forceinline__ bool TraceAny( const SceneView& sv, const SceneBuffer
     {
         const float4 a = Load16( sb.nodes, 32u * node ), b = Load16( sb.nodes, 32u * node + 16u );
         cnt.nodes++;
-        const uint32_t escape = __float_as_uint( b.z ), leaf = __float_as_uint( b.w );
+        const uint32_t link = __float_as_uint( b.z ), leaf = __float_as_uint( b.w );
         const bool boxHit = RayBox( o, inv, nx, ny, nz, a, b, tMax );
-        if ( boxHit && leaf == kInnerNode )
+        if ( boxHit && !( link & kLeafFlag ) )
         {
-            node = node + 1;
+            node = leaf; // first child
             continue;
         }
-        node = escape;
+        node = link & ~kLeafFlag;
         if ( !boxHit ) continue;
         const uint32_t first = leaf & kLeafFirstMask, count = ( leaf >> 28 ) + 1;
         for ( uint32_t k = 0; k < count; ++k )
@@ -417,6 +418,38 @@ __device__ __forceinline__ f3 Environment( const SceneView& sv, f3 v )
 
 constexpr int kBlock = 256;
 
+// Path id -> pixel.  Path ids run sample-major (id = local sample * pixels + slot) and a slot is a pixel in
+// tile order: the part of the image that 16 x 16 tiles cover, tile by tile and row-major inside a tile, then the
+// columns right of it, then the rows below.  256 consecutive path ids - one unit of work, four wave loads - are
+// one tile, so the rays a wave traces together start from neighbouring surface points.
+struct PixelOrder
+{
+    uint32_t width, height;
+};
+
+__device__ __forceinline__ void SlotToPixel( PixelOrder po, uint32_t slot, uint32_t* row, uint32_t* col )
+{
+    const uint32_t tiledW = po.width & ~15u, tiledH = po.height & ~15u, tiled = tiledW * tiledH;
+    if ( slot < tiled )
+    {
+        const uint32_t tile = slot >> 8, k = slot & 255u, tilesX = tiledW >> 4;
+        *row = ( tile / tilesX ) * 16u + ( k >> 4 );
+        *col = ( tile % tilesX ) * 16u + ( k & 15u );
+        return;
+    }
+    slot -= tiled;
+    const uint32_t rightW = po.width - tiledW;
+    if ( slot < rightW * po.height )
+    {
+        *row = slot / rightW;
+        *col = tiledW + slot % rightW;
+        return;
+    }
+    slot -= rightW * po.height;
+    *row = tiledH + slot / tiledW;
+    *col = slot % tiledW;
+}
+
 // Primary rays: pixel position, jitter, normalised direction (src/path_tracer.cpp:183-189,
 // src/anti_aliasing.cpp:89-92).  Path id = local sample * pixels + pixel.
 __global__ __launch_bounds__( kBlock ) void RaygenKernel( CameraFrame cam, RngParams rng, PathBuffers pb, uint32_t width,
@@ -425,8 +458,10 @@ __global__ __launch_bounds__( kBlock ) void RaygenKernel( CameraFrame cam, RngPa
     const uint32_t numPixels = width * height;
     for ( uint32_t p = blockIdx.x * kBlock + threadIdx.x; p < numPaths; p += gridDim.x * kBlock )
     {
-        const uint32_t pixel = p % numPixels, sample = sampleBegin + p / numPixels;
-        const uint32_t row = pixel / width, col = pixel % width;
+        const uint32_t sample = sampleBegin + p / numPixels;
+        uint32_t row, col;
+        SlotToPixel( PixelOrder{ width, height }, p % numPixels, &row, &col );
+        const uint32_t pixel = row * width + col;
         const f3 position = F3( cam.position ), UL = F3( cam.UL ), dU = F3( cam.dU ), dV = F3( cam.dV );
         f3 imagePlanePos = UL + dV * static_cast< float >( row ) + dU * static_cast< float >( col );
         // RandFloat( -0.5f, 0.5f ) = Rand() * ( h - l ) + l (src/utils/random.cpp:18-21).  The reference as
@@ -637,13 +672,13 @@ __global__ __launch_bounds__( kBlock ) PT_EXTEND_OCCUPANCY void ExtendKernel( Sc
             if ( go )
             {
                 const float4 a = Load16( sb.nodes, 32u * node ), b = Load16( sb.nodes, 32u * node + 16u );
-                const uint32_t escape = __float_as_uint( b.z ), word = __float_as_uint( b.w );
+                const uint32_t link = __float_as_uint( b.z ), word = __float_as_uint( b.w );
                 const bool boxHit = RayBox( o, inv, nx, ny, nz, a, b, h.t );
-                if ( boxHit && word == kInnerNode )
-                    node = node + 1;
+                if ( boxHit && !( link & kLeafFlag ) )
+                    node = word; // first child
                 else
                 {
-                    node = escape;
+                    node = link & ~kLeafFlag;
                     if ( boxHit ) leaf = word;
                 }
             }
@@ -749,13 +784,13 @@ __global__ __launch_bounds__( kBlock ) PT_CONNECT_OCCUPANCY void ConnectKernel( 
             if ( go )
             {
                 const float4 a = Load16( sb.nodes, 32u * node ), b = Load16( sb.nodes, 32u * node + 16u );
-                const uint32_t escape = __float_as_uint( b.z ), word = __float_as_uint( b.w );
+                const uint32_t link = __float_as_uint( b.z ), word = __float_as_uint( b.w );
                 const bool boxHit = RayBox( o, inv, nx, ny, nz, a, b, tMax );
-                if ( boxHit && word == kInnerNode )
-                    node = node + 1;
+                if ( boxHit && !( link & kLeafFlag ) )
+                    node = word; // first child
                 else
                 {
-                    node = escape;
+                    node = link & ~kLeafFlag;
                     if ( boxHit ) leaf = word;
                 }
             }
@@ -890,7 +925,9 @@ __global__ __launch_bounds__( kBlock ) void ShadeKernel( SceneView sv, RngParams
                     const int tex = __float_as_int( m0.w );
                     if ( tex >= 0 ) Kd = Kd * TextureFetch( sv, tex, tu, tv );
                     sf.F   = Kd / kPi; // BRDF::F (src/resource/material.cpp:15-18)
-                    pixel  = p % numPixels;
+                    uint32_t row, col;
+                    SlotToPixel( PixelOrder{ width, height }, p % numPixels, &row, &col );
+                    pixel  = row * width + col;
                     sample = sampleBegin + p / numPixels;
                 }
             }
@@ -1046,14 +1083,18 @@ __global__ __launch_bounds__( kBlock ) void ResolveKernel( SceneView sv, PathBuf
 }
 
 // totalColor += Li( sample ) in sample order (path_tracer.cpp:185-191); film.w counts the samples
-__global__ __launch_bounds__( kBlock ) void FilmKernel( PathBuffers pb, float4* film, uint32_t numPixels, uint32_t samplesInPass )
+__global__ __launch_bounds__( kBlock ) void FilmKernel( PathBuffers pb, float4* film, uint32_t width, uint32_t height, uint32_t samplesInPass )
 {
-    for ( uint32_t pixel = blockIdx.x * kBlock + threadIdx.x; pixel < numPixels; pixel += gridDim.x * kBlock )
+    const uint32_t numPixels = width * height;
+    for ( uint32_t slot = blockIdx.x * kBlock + threadIdx.x; slot < numPixels; slot += gridDim.x * kBlock )
     {
+        uint32_t row, col;
+        SlotToPixel( PixelOrder{ width, height }, slot, &row, &col );
+        const uint32_t pixel = row * width + col;
         float4 f = film[pixel];
         for ( uint32_t s = 0; s < samplesInPass; ++s )
         {
-            const float4 L = pb.rad[static_cast< size_t >( s ) * numPixels + pixel];
+            const float4 L = pb.rad[static_cast< size_t >( s ) * numPixels + slot];
             f.x += L.x;
             f.y += L.y;
             f.z += L.z;
@@ -1196,9 +1237,10 @@ void LaunchResolve( const LaunchCfg& cfg, const SceneView& sv, const PathBuffers
     hipLaunchKernelGGL( ResolveKernel, UnitGrid( pb ), dim3( kBlock ), 0, cfg.stream, sv, pb, bounce );
 }
 
-void LaunchFilm( const LaunchCfg& cfg, const PathBuffers& pb, float4* film, uint32_t numPixels, uint32_t samplesInPass )
+void LaunchFilm( const LaunchCfg& cfg, const PathBuffers& pb, float4* film, uint32_t width, uint32_t height, uint32_t samplesInPass )
 {
-    hipLaunchKernelGGL( FilmKernel, dim3( GridFor( cfg, numPixels ) ), dim3( kBlock ), 0, cfg.stream, pb, film, numPixels, samplesInPass );
+    hipLaunchKernelGGL( FilmKernel, dim3( GridFor( cfg, static_cast< uint64_t >( width ) * height ) ), dim3( kBlock ), 0, cfg.stream, pb, film, width,
+                        height, samplesInPass );
 }
 
 void LaunchTonemap( const LaunchCfg& cfg, const float4* film, float* linearOut, float* tonemappedOut, uint32_t numPixels, float exposure,

@@ -1,7 +1,9 @@
 // Device-side data layout and launch interface of the path-tracing core (gfx950).
 //
 // All scene data is rewritten at upload into layouts chosen for 16-byte coalescable loads:
-//   nodes      2 x float4 per node (32 B): {lo.xyz, hi.x} {hi.y, hi.z, escape, leaf}
+//   nodes      2 x float4 per node (32 B): {lo.xyz, hi.x} {hi.y, hi.z, link, word}; link = node to go to after
+//              this node's subtree (top bit: leaf), word = leaf descriptor or first child.  The first numTopNodes
+//              nodes are the top of the tree in breadth-first order, the rest follows in the reference's pre-order
 //   prims      3 x float4 per primitive (48 B): triangle {v0, tag 0} {v1 - v0} {v2 - v0};
 //              sphere {centre, tag 1} {radius, sphere index}
 //   triShade   7 x float4 per triangle primitive (112 B): n0 n1 n2 t0 t1 t2 uv0 uv1 uv2 material
@@ -17,11 +19,13 @@
 namespace ptd
 {
 
-constexpr uint32_t kInnerNode    = 0xFFFFFFFFu; // DevNode leaf word of an inner node
+constexpr uint32_t kInnerNode    = 0xFFFFFFFFu; // "no leaf pending" in the traversal state; never a valid leaf word
+constexpr uint32_t kLeafFlag     = 0x80000000u; // top bit of a node's link word
+constexpr uint32_t kTopNodes     = 4095;          // default size of the breadth-first ordered top of the tree
 constexpr uint32_t kLeafFirstMask = 0x0FFFFFFFu; // leaf word: low 28 bits first primitive, high 4 bits count - 1
 constexpr int kMaxLeafShapes     = 16;
 // nodes and primitive records are read through 32-bit-offset buffer descriptors: each array stays under 4 GiB
-constexpr uint32_t kMaxNodes = 0xFFFFFFFFu / 32u - 1u;
+constexpr uint32_t kMaxNodes = 0x7FFFFFFFu / 32u - 1u;
 constexpr uint32_t kMaxPrims = 0xFFFFFFFFu / 48u - 1u;
 constexpr uint32_t kTagTriangle = 0, kTagSphere = 1;
 
@@ -62,6 +66,7 @@ struct SceneView
     const DevLight* lights;
     const float4* skybox; // 6 * w * h texels or nullptr
     uint32_t numNodes;
+    uint32_t numTopNodes;
     uint32_t numPrims;
     uint32_t numSpheres;
     uint32_t numLights;
@@ -143,7 +148,7 @@ void LaunchShade( const LaunchCfg& cfg, const SceneView& sv, const RngParams& rn
                   int maxDepth, uint32_t width, uint32_t height, uint32_t sampleBegin, uint32_t numPaths, uint64_t* stats );
 void LaunchConnect( const LaunchCfg& cfg, const SceneView& sv, const PathBuffers& pb, int bounce, uint64_t* stats );
 void LaunchResolve( const LaunchCfg& cfg, const SceneView& sv, const PathBuffers& pb, int bounce );
-void LaunchFilm( const LaunchCfg& cfg, const PathBuffers& pb, float4* film, uint32_t numPixels, uint32_t samplesInPass );
+void LaunchFilm( const LaunchCfg& cfg, const PathBuffers& pb, float4* film, uint32_t width, uint32_t height, uint32_t samplesInPass );
 void LaunchTonemap( const LaunchCfg& cfg, const float4* film, float* linearOut, float* tonemappedOut, uint32_t numPixels,
                     float exposure, float gamma, uint32_t op );
 void LaunchTraceClosest( const LaunchCfg& cfg, const SceneView& sv, uint64_t n, const float* origins, const float* dirs,
