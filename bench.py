@@ -4,7 +4,7 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
 
-Workload (BASELINE.json configs[2], the configuration the metric is quoted on): the Sponza scene of
+Workload (the configuration the headline metric is quoted on): the Sponza scene of
 resources/scenes/sponza.json at 1920x1080, depth 5.  sponza.obj and eight of its textures are not part of the
 reference checkout, so the scene is the procedural atrium stand-in of pathtracer_amd/host/generators.cpp with
 the same triangle count (262,267), camera, light and 24 textured 1024^2 materials; `data` says so.
@@ -17,8 +17,9 @@ onto rank 0 with one RCCL reduce, inside the timed region.  --steps 64 on one GP
 The JSON line carries `roofline` for the dominant kernel (closest-hit traversal or shadow-ray traversal,
 whichever took longer): algorithmic bytes from the kernel's own counters (32 B per node fetched, 48 B per
 triangle test, 84 / 16 B per sphere test, 48 / 36 B per ray in + out) over the kernel time measured with HIP
-events on the stream the kernels run on; and `cpu_baseline`: the CPU restatement of the same path
-(oracle/pt_oracle.c, OpenMP) timed on this host over a bounded sample of the same frame.
+events on the stream the kernels run on; and `cpu_baseline`: the reference's own compiled hot path
+(oracle/_ref/libptref.so) or, without it, the CPU restatement (oracle/pt_oracle.c), both OpenMP, timed on this
+host over a bounded sample of the same frame.
 """
 import argparse
 import glob
