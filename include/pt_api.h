@@ -288,6 +288,13 @@ int pt_film_device_ptr( PtScene* scene, void** device_ptr, uint64_t* bytes );
 /* Clears the film and the counters. */
 int pt_clear_film( PtScene* scene );
 
+/* Checkpoint and resume of a long render: copies the film (image_width * image_height * 4 floats: sum r, sum g,
+ * sum b, sample count per pixel, row-major) to or from host memory.  After pt_upload_film, pt_render with
+ * PT_RENDER_ACCUMULATE and the remaining sample range continues the picture; because the film holds plain sums
+ * in sample order, the result is bit-identical to an uninterrupted render.  No counterpart in the reference. */
+int pt_download_film( PtScene* scene, float* film_rgba );
+int pt_upload_film( PtScene* scene, const float* film_rgba );
+
 /* Replaces: Scene::~Scene / BVH::~BVH (src/scene.cpp:13-19, src/bvh.cpp:7-13). */
 int pt_destroy_scene( PtScene* scene );
 

@@ -57,6 +57,8 @@ def lib():
         L.pt_trace_any.argtypes = [C.c_void_p, C.c_uint64] + [C.c_void_p] * 6
         L.pt_film_device_ptr.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
         L.pt_clear_film.argtypes = [C.c_void_p]
+        L.pt_download_film.argtypes = [C.c_void_p, C.c_void_p]
+        L.pt_upload_film.argtypes = [C.c_void_p, C.c_void_p]
         L.pt_destroy_scene.argtypes = [C.c_void_p]
         _LIB = L
     return _LIB
@@ -135,6 +137,18 @@ class DeviceScene:
 
     def clear_film(self):
         _check(lib().pt_clear_film(self._h))
+
+    def download_film(self):
+        """(H, W, 4) float32: sum r, sum g, sum b and sample count per pixel."""
+        film = np.zeros((self.height, self.width, 4), np.float32)
+        _check(lib().pt_download_film(self._h, film.ctypes.data))
+        return film
+
+    def upload_film(self, film):
+        film = _f32(film)
+        if film.shape != (self.height, self.width, 4):
+            raise ValueError(f"film must be ({self.height}, {self.width}, 4)")
+        _check(lib().pt_upload_film(self._h, film.ctypes.data))
 
     def film_device_ptr(self):
         ptr, nbytes = C.c_void_p(), C.c_uint64()

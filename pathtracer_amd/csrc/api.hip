@@ -761,6 +761,25 @@ int pt_film_device_ptr( PtScene* s, void** device_ptr, uint64_t* bytes )
     return PT_OK;
 }
 
+int pt_download_film( PtScene* s, float* film_rgba )
+{
+    if ( !s || !film_rgba ) return Fail( PT_ERR_INVALID_ARG, "pt_download_film: null argument" );
+    HIP_TRY( hipSetDevice( s->device ) );
+    HIP_TRY( hipMemcpyAsync( film_rgba, s->film.ptr, s->film.bytes, hipMemcpyDeviceToHost, s->stream ) );
+    HIP_TRY( hipStreamSynchronize( s->stream ) );
+    return PT_OK;
+}
+
+int pt_upload_film( PtScene* s, const float* film_rgba )
+{
+    if ( !s || !film_rgba ) return Fail( PT_ERR_INVALID_ARG, "pt_upload_film: null argument" );
+    HIP_TRY( hipSetDevice( s->device ) );
+    HIP_TRY( hipMemcpyAsync( s->film.ptr, film_rgba, s->film.bytes, hipMemcpyHostToDevice, s->stream ) );
+    HIP_TRY( hipStreamSynchronize( s->stream ) );
+    s->rendered = true;
+    return PT_OK;
+}
+
 int pt_trace_closest( PtScene* s, uint64_t n, const float* origins, const float* directions, int32_t* prim, float* t, float* u, float* v,
                       uint32_t* nodes_visited, uint32_t* prim_tests )
 {

@@ -221,3 +221,35 @@ def test_film_tensor_and_single_rank_rccl_reduce(device_scenes):
         assert_bits_equal(after, host_film, "film after a one-rank reduce")
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("width,height", [(53, 37), (7, 5), (16, 40), (33, 16)])
+def test_image_sizes_that_do_not_fill_whole_tiles(width, height, scenes):
+    """Path ids follow 16 x 16 pixel tiles, then the columns right of the tiled area, then the rows below it:
+    sizes that exercise each part (and an image smaller than one tile) must give the checker's image."""
+    scene = scenes["mixed"].with_image(width, height)
+    desc = scene.to_desc()
+    with api.DeviceScene(desc) as dev:
+        dev.render(3, seed=4)
+        lin, _, stats = dev.readback()
+        want, ostats = checker.OracleScene(desc).li_image(3, seed=4)
+        radiance_close(lin, want / np.float32(3), f"{width}x{height}")
+        assert stats.samples == width * height * 3 and stats.rays_closest == ostats["rays_closest"]
+
+
+def test_film_checkpoint_and_resume_is_bit_identical(scenes):
+    """pt_download_film / pt_upload_film: a render interrupted after 3 of 8 samples, carried through host memory
+    into a freshly uploaded scene and continued, equals the uninterrupted one."""
+    desc = scenes["cornell"].with_image(40, 24).to_desc()
+    with api.DeviceScene(desc) as dev:
+        dev.render(8, seed=6)
+        whole, _, _ = dev.readback()
+        dev.render(8, 0, 3, seed=6)
+        checkpoint = dev.download_film()
+        assert (checkpoint[..., 3] == 3).all()
+    with api.DeviceScene(desc) as dev:
+        dev.upload_film(checkpoint)
+        dev.render(8, 3, 8, seed=6, accumulate=True)
+        resumed, _, _ = dev.readback()
+        assert (dev.download_film()[..., 3] == 8).all()
+    assert_bits_equal(whole, resumed, "resumed render")
