@@ -9,10 +9,10 @@ resources/scenes/sponza.json at 1920x1080, depth 5.  sponza.obj and eight of its
 reference checkout, so the scene is the procedural atrium stand-in of pathtracer_amd/host/generators.cpp with
 the same triangle count (262,267), camera, light and 24 textured 1024^2 materials; `data` says so.
 
-One step = one pass of the hot path over one batch: --spp-per-step samples of every pixel (default 16), i.e.
-1920 * 1080 * 16 = 33.2 M pixel samples per GPU and step.  Every rank renders its own sample indices of the
+One step = one pass of the hot path over one batch: --spp-per-step samples of every pixel (default 32, all in
+flight at once: 66.4 M paths), i.e. 1920 * 1080 * 32 = 66.4 M pixel samples per GPU and step.  Every rank renders its own sample indices of the
 same frame (weak scaling: per-GPU work per step is fixed); after the last step the per-GPU films are summed
-onto rank 0 with one RCCL reduce, inside the timed region.  --steps 64 on one GPU is the full 1024 spp frame.
+onto rank 0 with one RCCL reduce, inside the timed region.  --steps 32 on one GPU is the full 1024 spp frame.
 
 The JSON line carries `roofline` for the dominant kernel (closest-hit traversal or shadow-ray traversal,
 whichever took longer): algorithmic bytes from the kernel's own counters (32 B per node fetched, 48 B per
@@ -37,9 +37,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=16)
+    p.add_argument("--steps", type=int, default=8)
     p.add_argument("--warmup", type=int, default=2)
-    p.add_argument("--spp-per-step", type=int, default=16)
+    p.add_argument("--spp-per-step", type=int, default=32)
     p.add_argument("--width", type=int, default=1920)
     p.add_argument("--height", type=int, default=1080)
     p.add_argument("--triangles", type=int, default=262267)

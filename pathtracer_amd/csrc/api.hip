@@ -617,11 +617,15 @@ int pt_render( PtScene* s, const PtRenderParams* p )
 
     const uint64_t pixels = static_cast< uint64_t >( s->width ) * s->height;
     const int totalSamples = p->sample_end - p->sample_begin;
-    // samples of every pixel in flight at once: as many as fit 16 Mi paths and 24 GiB of path state
+    // Samples of every pixel in flight at once: as many as fit 64 Mi paths, 24 GiB of path state and 32-bit shadow
+    // record indices.  Large passes matter: every traversal launch ends with waves draining their last, longest
+    // rays, a fixed cost per launch (measured at 1080p: 2 / 8 / 32 samples per pass = 1.59 / 2.44 / 2.76 Grays/s).
     uint64_t perPass = p->samples_per_pass > 0 ? static_cast< uint64_t >( p->samples_per_pass ) : 0;
     if ( perPass == 0 )
     {
-        const uint64_t maxPaths = std::min< uint64_t >( 16ull << 20, ( 24ull << 30 ) / s->bytesPerPathFixed );
+        const uint64_t slots = s->view.shadowSlots > 0 ? s->view.shadowSlots : 1;
+        uint64_t maxPaths = std::min< uint64_t >( 64ull << 20, ( 24ull << 30 ) / s->bytesPerPathFixed );
+        maxPaths = std::min< uint64_t >( maxPaths, 0xfffffffeull / slots );
         perPass = std::max< uint64_t >( 1, maxPaths / pixels );
     }
     if ( perPass > static_cast< uint64_t >( totalSamples ) ) perPass = totalSamples > 0 ? totalSamples : 1;
