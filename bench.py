@@ -156,7 +156,10 @@ def main():
                     "launches": klaunch, "bytes_per_ray": round(kbytes / max(1, krays), 1),
                     "grays_per_s_in_kernel": round(krays / (kms * 1e-3) / 1e9, 3) if kms > 0 else 0.0,
                     "nodes_per_ray": round(knodes / max(1, krays), 2),
-                    "lanes_per_node_step": round(knodes / max(1, ksteps), 2)}
+                    "lanes_per_node_step": round(knodes / max(1, ksteps), 2),
+                    "note": "algorithmic bytes = the reference's per-ray byte model times the kernel's own counters; "
+                            "`traffic` is what left the L2 (the 29 MB of nodes and primitive records are served from "
+                            "L1 / L2 / Infinity Cache after the first touch), so the fraction can exceed 1"}
 
         # what a plain device-to-device copy reaches on this GPU (read + write bytes), beside the nominal peak
         if world == 1:
