@@ -570,36 +570,32 @@ __device__ __forceinline__ void FlushWaveCounter( uint64_t* stats, int slot, uin
 #ifndef PT_TRAVERSE_BURST
 #define PT_TRAVERSE_BURST 6
 #endif
-// occupancy target of ExtendKernel in waves per SIMD: 7 (72 VGPRs, a few spilled around the leaf phase) measured
-// 7 % faster than the compiler's own choice of 6 (80 VGPRs), 8 (64 VGPRs, spills in the node loop) 6 % slower
-#ifndef PT_EXTEND_WAVES
-#define PT_EXTEND_WAVES 7
-#endif
-#define PT_EXTEND_OCCUPANCY __attribute__( ( amdgpu_waves_per_eu( PT_EXTEND_WAVES, PT_EXTEND_WAVES ) ) )
-#ifdef PT_CONNECT_WAVES
-#define PT_CONNECT_OCCUPANCY __attribute__( ( amdgpu_waves_per_eu( PT_CONNECT_WAVES, PT_CONNECT_WAVES ) ) )
-#else
-#define PT_CONNECT_OCCUPANCY
-#endif
 // The traversal kernels keep the first kLdsTopNodes nodes of the (breadth-first ordered) node array in LDS, one copy
 // per workgroup, and read them with ds_read instead of going through the texture addresser and the L1 - the
-// busiest unit of these kernels.  704 nodes = 22 KB per workgroup is what seven workgroups per CU leave room for
-// (measured 384 / 511 / 640 / 704: extend 15.9 / 15.2 / 14.9 / 14.9 ms against 17.6 ms without).
+// busiest unit of these kernels.  Large workgroups share one copy between more waves: 768 threads (12 waves), two
+// workgroups per CU (6 waves per SIMD, 80 VGPRs), 2,400 nodes = 75 KB each.  Measured, extend per launch of
+// 66.4 M paths: no LDS copy, 256 threads x 7 per CU, 17.6 ms; 384 / 704 nodes in that shape 15.9 / 14.9 ms;
+// 512 threads x 3 with 1,600 nodes 14.1 ms; 768 x 2 with 2,400 nodes 14.0 ms.  (Without the copy 7 waves per SIMD
+// beat 6 by 7 % and 8, which spills in the node loop, lost 6 %.)
 #ifndef PT_LDS_TOP_NODES
-#define PT_LDS_TOP_NODES 704
+#define PT_LDS_TOP_NODES 2400
 #endif
-#ifndef PT_EXTEND_BLOCK
-#define PT_EXTEND_BLOCK 256
+#ifndef PT_TRAVERSE_BLOCK
+#define PT_TRAVERSE_BLOCK 768
 #endif
+#ifndef PT_TRAVERSE_WAVES
+#define PT_TRAVERSE_WAVES 6
+#endif
+#define PT_TRAVERSE_OCCUPANCY __attribute__( ( amdgpu_waves_per_eu( PT_TRAVERSE_WAVES, PT_TRAVERSE_WAVES ) ) )
 constexpr uint32_t kLdsTopNodes = PT_LDS_TOP_NODES;
-constexpr int kExtendBlock      = PT_EXTEND_BLOCK;
+constexpr int kTraverseBlock    = PT_TRAVERSE_BLOCK;
 constexpr int kRefillLanes   = PT_REFILL_LANES;
 constexpr int kLeafLanes     = PT_LEAF_LANES;
 constexpr int kTraverseBurst = PT_TRAVERSE_BURST;
 
 // Closest hits of the rays entering `bounce`: BVH::Intersect (src/bvh.cpp:230-268) under Scene::Intersect
 // (src/scene.cpp:370-373).
-__global__ __launch_bounds__( kExtendBlock ) PT_EXTEND_OCCUPANCY void ExtendKernel( SceneView sv, PathBuffers pb, int bounce, uint32_t numPaths, uint64_t* stats )
+__global__ __launch_bounds__( kTraverseBlock ) PT_TRAVERSE_OCCUPANCY void ExtendKernel( SceneView sv, PathBuffers pb, int bounce, uint32_t numPaths, uint64_t* stats )
 {
     UnitStream stream{ pb.cursors + 2 * bounce, bounce == 0 ? nullptr : UnitCount( pb, bounce - 1, kCountNextPaths, 0 ), pb.units, kUnitPaths, numPaths };
     const uint32_t* items = bounce == 0 ? nullptr : pb.queue[bounce & 1];
@@ -609,7 +605,7 @@ __global__ __launch_bounds__( kExtendBlock ) PT_EXTEND_OCCUPANCY void ExtendKern
     const uint32_t topCount = kLdsTopNodes < sv.numTopNodes ? kLdsTopNodes : sv.numTopNodes;
     if ( kLdsTopNodes > 0 )
     {
-        for ( uint32_t i = threadIdx.x; i < 2 * topCount; i += kExtendBlock ) topLds[i] = Load16( sb.nodes, 16u * i );
+        for ( uint32_t i = threadIdx.x; i < 2 * topCount; i += kTraverseBlock ) topLds[i] = Load16( sb.nodes, 16u * i );
         __syncthreads();
     }
     // node: the node to visit next (or, while a leaf is pending, the node to go to after it); leaf: pending leaf word
@@ -723,7 +719,7 @@ __global__ __launch_bounds__( kExtendBlock ) PT_EXTEND_OCCUPANCY void ExtendKern
 // Visibility of the queued shadow rays: BVH::Occluded (src/bvh.cpp:270-310) under Scene::Occluded
 // (src/scene.cpp:381-384), same scheduling as ExtendKernel.  One work item per shadow record; an occluded
 // record gets the distance -2 written back, so that ResolveKernel leaves it out of the sum.
-__global__ __launch_bounds__( kBlock ) PT_CONNECT_OCCUPANCY void ConnectKernel( SceneView sv, PathBuffers pb, int bounce, uint64_t* stats )
+__global__ __launch_bounds__( kTraverseBlock ) PT_TRAVERSE_OCCUPANCY void ConnectKernel( SceneView sv, PathBuffers pb, int bounce, uint64_t* stats )
 {
     UnitStream stream{ pb.cursors + 2 * bounce + 1, UnitCount( pb, bounce, kCountShadowRays, 0 ), pb.units, kUnitPaths * pb.shadowSlots, 0u };
     const uint32_t end      = sv.numNodes;
@@ -733,7 +729,7 @@ __global__ __launch_bounds__( kBlock ) PT_CONNECT_OCCUPANCY void ConnectKernel( 
     const uint32_t topCount = kLdsTopNodes < sv.numTopNodes ? kLdsTopNodes : sv.numTopNodes;
     if ( kLdsTopNodes > 0 )
     {
-        for ( uint32_t i = threadIdx.x; i < 2 * topCount; i += kBlock ) topLds[i] = Load16( sb.nodes, 16u * i );
+        for ( uint32_t i = threadIdx.x; i < 2 * topCount; i += kTraverseBlock ) topLds[i] = Load16( sb.nodes, 16u * i );
         __syncthreads();
     }
     uint32_t rec = kNoRay, node = end, leaf = kInnerNode;
@@ -1245,8 +1241,8 @@ static dim3 UnitGrid( const PathBuffers& pb ) { return dim3( ( pb.units + kBlock
 void TraversalOccupancy( int* extendBlocksPerCu, int* connectBlocksPerCu )
 {
     int e = 0, c = 0;
-    if ( hipOccupancyMaxActiveBlocksPerMultiprocessor( &e, ExtendKernel, kExtendBlock, 0 ) != hipSuccess || e < 1 ) e = 4;
-    if ( hipOccupancyMaxActiveBlocksPerMultiprocessor( &c, ConnectKernel, kBlock, 0 ) != hipSuccess || c < 1 ) c = 4;
+    if ( hipOccupancyMaxActiveBlocksPerMultiprocessor( &e, ExtendKernel, kTraverseBlock, 0 ) != hipSuccess || e < 1 ) e = 4;
+    if ( hipOccupancyMaxActiveBlocksPerMultiprocessor( &c, ConnectKernel, kTraverseBlock, 0 ) != hipSuccess || c < 1 ) c = 4;
     *extendBlocksPerCu  = e;
     *connectBlocksPerCu = c;
 }
@@ -1259,7 +1255,7 @@ void LaunchRaygen( const LaunchCfg& cfg, const CameraFrame& cam, const RngParams
 
 void LaunchExtend( const LaunchCfg& cfg, const SceneView& sv, const PathBuffers& pb, int bounce, uint32_t numPaths, uint64_t* stats )
 {
-    hipLaunchKernelGGL( ExtendKernel, dim3( cfg.extendBlocks ), dim3( kExtendBlock ), 0, cfg.stream, sv, pb, bounce, numPaths, stats );
+    hipLaunchKernelGGL( ExtendKernel, dim3( cfg.extendBlocks ), dim3( kTraverseBlock ), 0, cfg.stream, sv, pb, bounce, numPaths, stats );
 }
 
 void LaunchShade( const LaunchCfg& cfg, const SceneView& sv, const RngParams& rng, const PathBuffers& pb, int bounce, int maxDepth,
@@ -1275,7 +1271,7 @@ void LaunchShade( const LaunchCfg& cfg, const SceneView& sv, const RngParams& rn
 
 void LaunchConnect( const LaunchCfg& cfg, const SceneView& sv, const PathBuffers& pb, int bounce, uint64_t* stats )
 {
-    hipLaunchKernelGGL( ConnectKernel, dim3( cfg.connectBlocks ), dim3( kBlock ), 0, cfg.stream, sv, pb, bounce, stats );
+    hipLaunchKernelGGL( ConnectKernel, dim3( cfg.connectBlocks ), dim3( kTraverseBlock ), 0, cfg.stream, sv, pb, bounce, stats );
 }
 
 void LaunchResolve( const LaunchCfg& cfg, const SceneView& sv, const PathBuffers& pb, int bounce )
