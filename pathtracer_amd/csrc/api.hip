@@ -266,8 +266,8 @@ int Upload( PtScene* s, const PtSceneDesc* d, const std::vector< uint32_t >& esc
     {
         const PtBvhNode& n = d->nodes[i];
         float* o = &nodes[8ull * place[i]];
-        o[0] = n.aabb_min[0]; o[1] = n.aabb_min[1]; o[2] = n.aabb_min[2];
-        o[3] = n.aabb_max[0]; o[4] = n.aabb_max[1]; o[5] = n.aabb_max[2];
+        o[0] = n.aabb_min[0]; o[1] = n.aabb_min[1]; o[2] = n.aabb_max[0]; o[3] = n.aabb_max[1];
+        o[4] = n.aabb_min[2]; o[5] = n.aabb_max[2];
         // link word: where to go after this node's subtree, top bit set for a leaf; second word: the leaf's
         // primitives, or the first child of an inner node
         uint32_t link = place[escape[i]], word = place[i + 1 <= N ? i + 1 : N];

@@ -76,6 +76,13 @@ __device__ __forceinline__ float4 Load16( BufferDesc buffer, uint32_t byteOffset
     return make_float4( __uint_as_float( v.x ), __uint_as_float( v.y ), __uint_as_float( v.z ), __uint_as_float( v.w ) );
 }
 
+// One ds_read_b128
+__device__ __forceinline__ float4 LoadLds16( const float4* p )
+{
+    const u32x4 v = *reinterpret_cast< const u32x4* >( p );
+    return make_float4( __uint_as_float( v.x ), __uint_as_float( v.y ), __uint_as_float( v.z ), __uint_as_float( v.w ) );
+}
+
 struct SceneBuffers
 {
     BufferDesc nodes, prims;
@@ -152,17 +159,19 @@ __device__ __forceinline__ f3 MatMul( float4 c0, float4 c1, float4 c2, float4 c3
 
 // intersect::RayAABBFastest (src/intersection_tests.cpp:91-110): comparisons and selects only, so that a
 // NaN slab value behaves as on the CPU.
+// Node record: a = {lo.x, lo.y, hi.x, hi.y}, b = {lo.z, hi.z, link, word} - the x and y planes of either side sit
+// in adjacent registers, which is what the packed two-float subtract / multiply of the slab arithmetic wants.
 __device__ __forceinline__ bool RayBox( f3 o, f3 inv, bool nx, bool ny, bool nz, float4 a, float4 b, float maxT )
 {
     // Both early returns of the reference are folded into flags: once one of them would have fired the later
     // values are never looked at, so evaluating everything up front gives the same answer and lets the whole
     // 32-byte node be fetched with two 16-byte loads before any arithmetic.
-    float tMin  = ( ( nx ? a.w : a.x ) - o.x ) * inv.x;
-    float tMax  = ( ( nx ? a.x : a.w ) - o.x ) * inv.x;
-    float tyMin = ( ( ny ? b.x : a.y ) - o.y ) * inv.y;
-    float tyMax = ( ( ny ? a.y : b.x ) - o.y ) * inv.y;
-    float tzMin = ( ( nz ? b.y : a.z ) - o.z ) * inv.z;
-    float tzMax = ( ( nz ? a.z : b.y ) - o.z ) * inv.z;
+    float tMin  = ( ( nx ? a.z : a.x ) - o.x ) * inv.x;
+    float tMax  = ( ( nx ? a.x : a.z ) - o.x ) * inv.x;
+    float tyMin = ( ( ny ? a.w : a.y ) - o.y ) * inv.y;
+    float tyMax = ( ( ny ? a.y : a.w ) - o.y ) * inv.y;
+    float tzMin = ( ( nz ? b.y : b.x ) - o.z ) * inv.z;
+    float tzMax = ( ( nz ? b.x : b.y ) - o.z ) * inv.z;
     const bool missXY = ( tMin > tyMax ) | ( tyMin > tMax );
     if ( tyMin > tMin ) tMin = tyMin;
     if ( tyMax < tMax ) tMax = tyMax;
@@ -689,8 +698,8 @@ __global__ __launch_bounds__( kTraverseBlock ) PT_TRAVERSE_OCCUPANCY void Extend
                 float4 a, b;
                 if ( kLdsTopNodes > 0 && node < topCount )
                 {
-                    a = topLds[2 * node];
-                    b = topLds[2 * node + 1];
+                    a = LoadLds16( topLds + 2 * node );
+                    b = LoadLds16( topLds + 2 * node + 1 );
                 }
                 else
                 {
@@ -818,8 +827,8 @@ __global__ __launch_bounds__( kTraverseBlock ) PT_TRAVERSE_OCCUPANCY void Connec
                 float4 a, b;
                 if ( kLdsTopNodes > 0 && node < topCount )
                 {
-                    a = topLds[2 * node];
-                    b = topLds[2 * node + 1];
+                    a = LoadLds16( topLds + 2 * node );
+                    b = LoadLds16( topLds + 2 * node + 1 );
                 }
                 else
                 {

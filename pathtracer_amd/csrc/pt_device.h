@@ -1,7 +1,7 @@
 // Device-side data layout and launch interface of the path-tracing core (gfx950).
 //
 // All scene data is rewritten at upload into layouts chosen for 16-byte coalescable loads:
-//   nodes      2 x float4 per node (32 B): {lo.xyz, hi.x} {hi.y, hi.z, link, word}; link = node to go to after
+//   nodes      2 x float4 per node (32 B): {lo.x, lo.y, hi.x, hi.y} {lo.z, hi.z, link, word}; link = node to go to after
 //              this node's subtree (top bit: leaf), word = leaf descriptor or first child.  The first numTopNodes
 //              nodes are the top of the tree in breadth-first order, the rest follows in the reference's pre-order
 //   prims      3 x float4 per primitive (48 B): triangle {v0, tag 0} {v1 - v0} {v2 - v0};
