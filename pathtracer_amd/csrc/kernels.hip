@@ -500,7 +500,9 @@ constexpr uint32_t kNoRay = 0xFFFFFFFFu;
 
 __device__ __forceinline__ uint32_t WaveIndex() { return blockIdx.x * ( kBlock / 64 ) + ( threadIdx.x >> 6 ); }
 __device__ __forceinline__ uint32_t LaneIndex() { return threadIdx.x & 63u; }
-__device__ __forceinline__ uint32_t LanesSet( bool flag ) { return static_cast< uint32_t >( __popcll( __ballot( flag ) ) ); }
+// Lane mask of a predicate, straight from the compare (the library's __ballot takes an int and compares it again)
+__device__ __forceinline__ unsigned long long Ballot( bool flag ) { return __builtin_amdgcn_ballot_w64( flag ); }
+__device__ __forceinline__ uint32_t LanesSet( bool flag ) { return static_cast< uint32_t >( __popcll( Ballot( flag ) ) ); }
 __device__ __forceinline__ uint32_t LanesBelow( unsigned long long mask ) { return static_cast< uint32_t >( __popcll( mask & ( ( 1ull << LaneIndex() ) - 1ull ) ) ); }
 
 __device__ __forceinline__ uint32_t* UnitCount( const PathBuffers& pb, int bounce, int which, uint32_t unit )
@@ -512,7 +514,7 @@ __device__ __forceinline__ uint32_t* UnitCount( const PathBuffers& pb, int bounc
 // wave-uniform).
 __device__ __forceinline__ void SegmentAppend( bool flag, uint32_t value, uint32_t* segment, uint32_t& count )
 {
-    const unsigned long long mask = __ballot( flag );
+    const unsigned long long mask = Ballot( flag );
     if ( flag ) segment[count + LanesBelow( mask )] = value;
     count += static_cast< uint32_t >( __popcll( mask ) );
 }
@@ -630,7 +632,7 @@ __global__ __launch_bounds__( kTraverseBlock ) PT_TRAVERSE_OCCUPANCY void Extend
         const bool traversing = node != end && !atLeaf;
         const bool idle       = node == end && !atLeaf;
         const bool wantsRay   = idle && ( p != kNoRay || !stream.ended );
-        const unsigned long long mLeaf = __ballot( atLeaf ), mTrav = __ballot( traversing ), mRay = __ballot( wantsRay );
+        const unsigned long long mLeaf = Ballot( atLeaf ), mTrav = Ballot( traversing ), mRay = Ballot( wantsRay );
         if ( ( mLeaf | mTrav | mRay ) == 0 ) break;
 
         if ( mRay && ( __popcll( mRay ) >= kRefillLanes || ( mTrav | mLeaf ) == 0 ) )
@@ -639,7 +641,7 @@ __global__ __launch_bounds__( kTraverseBlock ) PT_TRAVERSE_OCCUPANCY void Extend
             if ( idle ) p = kNoRay;
             while ( !stream.ended )
             {
-                const unsigned long long mIdle = __ballot( idle && p == kNoRay );
+                const unsigned long long mIdle = Ballot( idle && p == kNoRay );
                 if ( mIdle == 0 ) break;
                 if ( stream.taken == stream.count )
                 {
@@ -669,7 +671,7 @@ __global__ __launch_bounds__( kTraverseBlock ) PT_TRAVERSE_OCCUPANCY void Extend
         if ( mLeaf && ( __popcll( mLeaf ) >= kLeafLanes || mTrav == 0 ) )
         {
             const uint32_t first = leaf & kLeafFirstMask, shapes = atLeaf ? ( leaf >> 28 ) + 1 : 0;
-            for ( uint32_t k = 0; __ballot( k < shapes ) != 0; ++k ) // bvh.cpp:247-250: every shape of the leaf, t shrinking
+            for ( uint32_t k = 0; Ballot( k < shapes ) != 0; ++k ) // bvh.cpp:247-250: every shape of the leaf, t shrinking
             {
                 bool isTri = false, isSphere = false;
                 if ( k < shapes )
@@ -753,7 +755,7 @@ __global__ __launch_bounds__( kTraverseBlock ) PT_TRAVERSE_OCCUPANCY void Connec
         const bool traversing = node != end && !atLeaf;
         const bool idle       = node == end && !atLeaf;
         const bool wantsRay   = idle && ( rec != kNoRay || !stream.ended );
-        const unsigned long long mLeaf = __ballot( atLeaf ), mTrav = __ballot( traversing ), mRay = __ballot( wantsRay );
+        const unsigned long long mLeaf = Ballot( atLeaf ), mTrav = Ballot( traversing ), mRay = Ballot( wantsRay );
         if ( ( mLeaf | mTrav | mRay ) == 0 ) break;
 
         if ( mRay && ( __popcll( mRay ) >= kRefillLanes || ( mTrav | mLeaf ) == 0 ) )
@@ -762,7 +764,7 @@ __global__ __launch_bounds__( kTraverseBlock ) PT_TRAVERSE_OCCUPANCY void Connec
             if ( idle ) rec = kNoRay;
             while ( !stream.ended )
             {
-                const unsigned long long mIdle = __ballot( idle && rec == kNoRay );
+                const unsigned long long mIdle = Ballot( idle && rec == kNoRay );
                 if ( mIdle == 0 ) break;
                 if ( stream.taken == stream.count )
                 {
@@ -794,7 +796,7 @@ __global__ __launch_bounds__( kTraverseBlock ) PT_TRAVERSE_OCCUPANCY void Connec
         {
             const uint32_t first = leaf & kLeafFirstMask;
             uint32_t shapes = atLeaf ? ( leaf >> 28 ) + 1 : 0;
-            for ( uint32_t k = 0; __ballot( k < shapes ) != 0; ++k ) // bvh.cpp:287-293: stop at the first hit
+            for ( uint32_t k = 0; Ballot( k < shapes ) != 0; ++k ) // bvh.cpp:287-293: stop at the first hit
             {
                 bool isTri = false, isSphere = false;
                 if ( k < shapes )
@@ -896,7 +898,7 @@ __global__ __launch_bounds__( kBlock ) void ShadeKernel( SceneView sv, RngParams
     uint32_t nSpheres = 0, waveShaded = 0;
     const uint32_t drawBase = 2u + static_cast< uint32_t >( bounce ) * static_cast< uint32_t >( sv.drawsPerBounce );
 
-    for ( uint32_t j = LaneIndex(); __ballot( j < limit ) != 0; j += 64u )
+    for ( uint32_t j = LaneIndex(); Ballot( j < limit ) != 0; j += 64u )
     {
         bool lit = false, deferred = false, alive = false, anyShadow = false;
         uint32_t p = 0, pixel = 0, sample = 0;
