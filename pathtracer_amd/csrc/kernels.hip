@@ -159,6 +159,8 @@ __device__ __forceinline__ f3 MatMul( float4 c0, float4 c1, float4 c2, float4 c3
 
 // intersect::RayAABBFastest (src/intersection_tests.cpp:91-110): comparisons and selects only, so that a
 // NaN slab value behaves as on the CPU.
+typedef float f2 __attribute__( ( ext_vector_type( 2 ) ) );
+
 // Node record: a = {lo.x, lo.y, hi.x, hi.y}, b = {lo.z, hi.z, link, word} - the x and y planes of either side sit
 // in adjacent registers, which is what the packed two-float subtract / multiply of the slab arithmetic wants.
 __device__ __forceinline__ bool RayBox( f3 o, f3 inv, bool nx, bool ny, bool nz, float4 a, float4 b, float maxT )
@@ -166,12 +168,12 @@ __device__ __forceinline__ bool RayBox( f3 o, f3 inv, bool nx, bool ny, bool nz,
     // Both early returns of the reference are folded into flags: once one of them would have fired the later
     // values are never looked at, so evaluating everything up front gives the same answer and lets the whole
     // 32-byte node be fetched with two 16-byte loads before any arithmetic.
-    float tMin  = ( ( nx ? a.z : a.x ) - o.x ) * inv.x;
-    float tMax  = ( ( nx ? a.x : a.z ) - o.x ) * inv.x;
-    float tyMin = ( ( ny ? a.w : a.y ) - o.y ) * inv.y;
-    float tyMax = ( ( ny ? a.y : a.w ) - o.y ) * inv.y;
-    float tzMin = ( ( nz ? b.y : b.x ) - o.z ) * inv.z;
-    float tzMax = ( ( nz ? b.x : b.y ) - o.z ) * inv.z;
+    // two planes per instruction: v_pk_add_f32 / v_pk_mul_f32 round each half exactly like the scalar forms
+    const f2 tNear = ( f2{ nx ? a.z : a.x, ny ? a.w : a.y } - f2{ o.x, o.y } ) * f2{ inv.x, inv.y };
+    const f2 tFar  = ( f2{ nx ? a.x : a.z, ny ? a.y : a.w } - f2{ o.x, o.y } ) * f2{ inv.x, inv.y };
+    const f2 tZ    = ( f2{ nz ? b.y : b.x, nz ? b.x : b.y } - f2{ o.z, o.z } ) * f2{ inv.z, inv.z };
+    float tMin = tNear.x, tMax = tFar.x;
+    const float tyMin = tNear.y, tyMax = tFar.y, tzMin = tZ.x, tzMax = tZ.y;
     const bool missXY = ( tMin > tyMax ) | ( tyMin > tMax );
     if ( tyMin > tMin ) tMin = tyMin;
     if ( tyMax < tMax ) tMax = tyMax;
@@ -629,10 +631,11 @@ __global__ __launch_bounds__( kTraverseBlock ) PT_TRAVERSE_OCCUPANCY void Extend
     for ( ;; )
     {
         const bool atLeaf     = leaf != kInnerNode;
-        const bool traversing = node != end && !atLeaf;
-        const bool idle       = node == end && !atLeaf;
-        const bool wantsRay   = idle && ( p != kNoRay || !stream.ended );
-        const unsigned long long mLeaf = Ballot( atLeaf ), mTrav = Ballot( traversing ), mRay = Ballot( wantsRay );
+        const bool idle       = node == end && !atLeaf; // a lane wants a ray if it is idle and has a result to store or the stream goes on
+        // masks built from single compares (a ballot of a compound predicate costs two more vector instructions)
+        const unsigned long long mLeaf = Ballot( atLeaf ), mEnd = Ballot( node == end );
+        const unsigned long long mTrav = ~mEnd & ~mLeaf;
+        const unsigned long long mRay  = mEnd & ~mLeaf & ( stream.ended ? Ballot( p != kNoRay ) : ~0ull );
         if ( ( mLeaf | mTrav | mRay ) == 0 ) break;
 
         if ( mRay && ( __popcll( mRay ) >= kRefillLanes || ( mTrav | mLeaf ) == 0 ) )
@@ -691,7 +694,7 @@ __global__ __launch_bounds__( kTraverseBlock ) PT_TRAVERSE_OCCUPANCY void Extend
         for ( int burst = 0; burst < kTraverseBurst; ++burst )
         {
             const bool go = node != end && leaf == kInnerNode;
-            const uint32_t active = LanesSet( go );
+            const uint32_t active = static_cast< uint32_t >( __popcll( Ballot( node != end ) & Ballot( leaf == kInnerNode ) ) );
             if ( burst && 2 * active < started ) break;
             waveNodes += active;
             waveSteps++;
@@ -752,10 +755,11 @@ __global__ __launch_bounds__( kTraverseBlock ) PT_TRAVERSE_OCCUPANCY void Connec
     for ( ;; )
     {
         const bool atLeaf     = leaf != kInnerNode;
-        const bool traversing = node != end && !atLeaf;
-        const bool idle       = node == end && !atLeaf;
-        const bool wantsRay   = idle && ( rec != kNoRay || !stream.ended );
-        const unsigned long long mLeaf = Ballot( atLeaf ), mTrav = Ballot( traversing ), mRay = Ballot( wantsRay );
+        const bool idle       = node == end && !atLeaf; // a lane wants a ray if it is idle and has a result to store or the stream goes on
+        // masks built from single compares (a ballot of a compound predicate costs two more vector instructions)
+        const unsigned long long mLeaf = Ballot( atLeaf ), mEnd = Ballot( node == end );
+        const unsigned long long mTrav = ~mEnd & ~mLeaf;
+        const unsigned long long mRay  = mEnd & ~mLeaf & ( stream.ended ? Ballot( rec != kNoRay ) : ~0ull );
         if ( ( mLeaf | mTrav | mRay ) == 0 ) break;
 
         if ( mRay && ( __popcll( mRay ) >= kRefillLanes || ( mTrav | mLeaf ) == 0 ) )
@@ -820,7 +824,7 @@ __global__ __launch_bounds__( kTraverseBlock ) PT_TRAVERSE_OCCUPANCY void Connec
         for ( int burst = 0; burst < kTraverseBurst; ++burst )
         {
             const bool go = node != end && leaf == kInnerNode;
-            const uint32_t active = LanesSet( go );
+            const uint32_t active = static_cast< uint32_t >( __popcll( Ballot( node != end ) & Ballot( leaf == kInnerNode ) ) );
             if ( burst && 2 * active < started ) break;
             waveNodes += active;
             waveSteps++;
