@@ -569,19 +569,22 @@ __device__ __forceinline__ void FlushWaveCounter( uint64_t* stats, int slot, uin
 // every lane is a small state machine - traversing, waiting at a leaf, or waiting for a ray - and the WAVE
 // decides what to do next:
 //   refill    lanes without a ray store their result and take the next entries of the wave's stream, once
-//             kRefillLanes lanes are waiting
+//             enough lanes are waiting (kExtendRefillLanes / kConnectRefillLanes)
 //   leaf      lanes waiting at a leaf run the primitive tests together, once kLeafLanes lanes are waiting
 //   traverse  otherwise: up to kTraverseBurst node visits for the traversing lanes
 // A phase also runs as soon as nothing else can make progress, so every lane terminates.  Per ray the sequence
 // of node visits and primitive tests is unchanged: a waiting lane does nothing, it never runs ahead.
-#ifndef PT_REFILL_LANES
-#define PT_REFILL_LANES 32
+#ifndef PT_EXTEND_REFILL_LANES
+#define PT_EXTEND_REFILL_LANES 16
+#endif
+#ifndef PT_CONNECT_REFILL_LANES
+#define PT_CONNECT_REFILL_LANES 32
 #endif
 #ifndef PT_LEAF_LANES
 #define PT_LEAF_LANES 12
 #endif
 #ifndef PT_TRAVERSE_BURST
-#define PT_TRAVERSE_BURST 6
+#define PT_TRAVERSE_BURST 3
 #endif
 // The traversal kernels keep the first kLdsTopNodes nodes of the (breadth-first ordered) node array in LDS, one copy
 // per workgroup, and read them with ds_read instead of going through the texture addresser and the L1 - the
@@ -602,7 +605,8 @@ __device__ __forceinline__ void FlushWaveCounter( uint64_t* stats, int slot, uin
 #define PT_TRAVERSE_OCCUPANCY __attribute__( ( amdgpu_waves_per_eu( PT_TRAVERSE_WAVES, PT_TRAVERSE_WAVES ) ) )
 constexpr uint32_t kLdsTopNodes = PT_LDS_TOP_NODES;
 constexpr int kTraverseBlock    = PT_TRAVERSE_BLOCK;
-constexpr int kRefillLanes   = PT_REFILL_LANES;
+constexpr int kExtendRefillLanes  = PT_EXTEND_REFILL_LANES;
+constexpr int kConnectRefillLanes = PT_CONNECT_REFILL_LANES;
 constexpr int kLeafLanes     = PT_LEAF_LANES;
 constexpr int kTraverseBurst = PT_TRAVERSE_BURST;
 
@@ -638,7 +642,7 @@ __global__ __launch_bounds__( kTraverseBlock ) PT_TRAVERSE_OCCUPANCY void Extend
         const unsigned long long mRay  = mEnd & ~mLeaf & ( stream.ended ? Ballot( p != kNoRay ) : ~0ull );
         if ( ( mLeaf | mTrav | mRay ) == 0 ) break;
 
-        if ( mRay && ( __popcll( mRay ) >= kRefillLanes || ( mTrav | mLeaf ) == 0 ) )
+        if ( mRay && ( __popcll( mRay ) >= kExtendRefillLanes || ( mTrav | mLeaf ) == 0 ) )
         {
             if ( idle && p != kNoRay ) pb.hit[p] = make_float4( h.t, h.u, h.v, __int_as_float( h.prim ) );
             if ( idle ) p = kNoRay;
@@ -762,7 +766,7 @@ __global__ __launch_bounds__( kTraverseBlock ) PT_TRAVERSE_OCCUPANCY void Connec
         const unsigned long long mRay  = mEnd & ~mLeaf & ( stream.ended ? Ballot( rec != kNoRay ) : ~0ull );
         if ( ( mLeaf | mTrav | mRay ) == 0 ) break;
 
-        if ( mRay && ( __popcll( mRay ) >= kRefillLanes || ( mTrav | mLeaf ) == 0 ) )
+        if ( mRay && ( __popcll( mRay ) >= kConnectRefillLanes || ( mTrav | mLeaf ) == 0 ) )
         {
             if ( idle && rec != kNoRay && occluded ) reinterpret_cast< float* >( pb.shDir )[4ull * rec + 3] = -2.0f;
             if ( idle ) rec = kNoRay;
