@@ -48,13 +48,16 @@ def parse():
     p.add_argument("--cpu-baseline-spp", type=int, default=64, help="most samples per pixel the CPU baseline renders (0 = skip)")
     p.add_argument("--cpu-baseline-seconds", type=float, default=20.0, help="CPU time the baseline sample is sized for")
     p.add_argument("--save-image", default="", help="write the tonemapped frame of rank 0 to this file")
+    p.add_argument("--rehearse-on-one-gpu", action="store_true",
+                   help="run all ranks on GPU 0 with the gloo backend: a dry run of the multi-process path on a one-GPU box "
+                        "(the numbers mean nothing)")
     return p.parse_args()
 
 
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.rehearse_on_one_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         if rank == 0:
@@ -71,7 +74,10 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
 
     def barrier():
         if dist is not None:
@@ -142,7 +148,8 @@ def main():
         # newest committed rocprofv3 --pmc summary of this same command (profiles/collect_pmc.sh); null without one
         traffic, traffic_source = None, None
         summaries = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
-        if summaries:
+        profiled_workload = (args.spp_per_step, args.width, args.height, args.triangles, args.texture_size) == (32, 1920, 1080, 262267, 1024)
+        if summaries and profiled_workload:   # the committed counters are per launch of the default workload
             try:
                 entry = json.load(open(summaries[-1])).get(kernel, {})
                 if "fabric_read_bytes" in entry:
