@@ -785,7 +785,7 @@ __global__ __launch_bounds__( kTraverseBlock ) PT_TRAVERSE_OCCUPANCY void Connec
                 {
                     rec = pb.shadowRays[stream.base + stream.taken + rank];
                     const float4 dir = pb.shDir[rec];
-                    o    = F3( pb.rayO[rec % capacity] );
+                    o    = F3( pb.rayO[pb.shadowSlots == 1 ? rec : rec % capacity] ); // record index = slot * capacity + path
                     d    = F3( dir );
                     tMax = dir.w;
                     inv  = F3( 1.0f / d.x, 1.0f / d.y, 1.0f / d.z ); // bvh.cpp:275-276
@@ -919,17 +919,19 @@ __global__ __launch_bounds__( kBlock ) void ShadeKernel( SceneView sv, RngParams
             p = items ? items[j] : segment + j;
             const float4 hr = pb.hit[p];
             const int prim  = __float_as_int( hr.w );
-            const f3 o = F3( pb.rayO[p] ), d = F3( pb.rayD[p] );
+            const f3 d = F3( pb.rayD[p] );
             T    = F3( pb.thr[cur][p] );
-            f3 L = bounce == 0 ? F3( 0.0f, 0.0f, 0.0f ) : F3( pb.rad[p] );
+            f3 L = F3( 0.0f, 0.0f, 0.0f ); // radiance so far: nothing at bounce 0; a hit at a later bounce does not touch it here
 
             if ( prim < 0 )
             {
+                if ( bounce != 0 ) L = F3( pb.rad[p] );
                 L = L + T * Environment( sv, d ); // path_tracer.cpp:116-120
                 pb.rad[p] = F4( L, 0.0f );
             }
             else
             {
+                const f3 o = F3( pb.rayO[p] );
                 const float t = hr.x, u = hr.y, v = hr.z;
                 sf.position = o + d * t; // Ray::Evaluate
                 float tu, tv;
