@@ -101,7 +101,7 @@ struct PtScene
     uint64_t bytesPerPathFixed = 0;
 
     // path state
-    DeviceBuffer rayO, rayD, thr0, thr1, rad, hit, shDir, shEst, queue0, queue1, shadowPaths, shadowRays, sphereQueue, counts, cursors;
+    DeviceBuffer rayO0, rayO1, rayD0, rayD1, thr0, thr1, rad, hit, shadowO, shDir, shEst, queue0, queue1, shadowPaths, shadowRays, sphereQueue, counts, cursors;
     PathBuffers paths{};
     DeviceBuffer sampleTable;
 
@@ -424,9 +424,9 @@ int Upload( PtScene* s, const PtSceneDesc* d, const std::vector< uint32_t >& esc
     s->width    = d->image_width;
     s->height   = d->image_height;
     s->maxDepth = d->max_depth;
-    // rayO, rayD, thr x2, rad, hit (16 B each), four path queues (4 B each), per shadow slot a 32 B record and a 4 B queue entry;
-    // the queues' extra round of entries is small against the 24 GiB budget this figure is used for
-    s->bytesPerPathFixed = 6 * 16 + 4 * 4 + 36ull * static_cast< uint64_t >( slots > 0 ? slots : 1 );
+    // ray origin, direction and throughput double buffered, hit, radiance, shadow origin (16 B each), four queues
+    // (4 B each), per shadow slot a 32 B record and a 4 B queue entry
+    s->bytesPerPathFixed = 9 * 16 + 4 * 4 + 36ull * static_cast< uint64_t >( slots > 0 ? slots : 1 );
 
     const size_t pixels = static_cast< size_t >( s->width ) * s->height;
     HIP_TRY( s->film.Allocate( pixels * 16 ) );
@@ -441,17 +441,20 @@ int EnsurePathBuffers( PtScene* s, uint64_t capacity )
 {
     if ( s->paths.capacity >= capacity ) return PT_OK;
     const uint64_t slots = s->view.shadowSlots > 0 ? s->view.shadowSlots : 1;
-    HIP_TRY( s->rayO.Allocate( capacity * 16 ) );
-    HIP_TRY( s->rayD.Allocate( capacity * 16 ) );
-    HIP_TRY( s->thr0.Allocate( capacity * 16 ) );
-    HIP_TRY( s->thr1.Allocate( capacity * 16 ) );
-    HIP_TRY( s->rad.Allocate( capacity * 16 ) );
-    HIP_TRY( s->hit.Allocate( capacity * 16 ) );
-    HIP_TRY( s->shDir.Allocate( capacity * slots * 16 ) );
-    HIP_TRY( s->shEst.Allocate( capacity * slots * 16 ) );
     // one queue segment of kUnitPaths entries per unit of paths, one length per bounce, queue and unit
     const uint64_t units   = ( capacity + kUnitPaths - 1 ) / kUnitPaths;
     const uint64_t entries = units * kUnitPaths;
+    HIP_TRY( s->rayO0.Allocate( entries * 16 ) );
+    HIP_TRY( s->rayO1.Allocate( entries * 16 ) );
+    HIP_TRY( s->rayD0.Allocate( entries * 16 ) );
+    HIP_TRY( s->rayD1.Allocate( entries * 16 ) );
+    HIP_TRY( s->thr0.Allocate( entries * 16 ) );
+    HIP_TRY( s->thr1.Allocate( entries * 16 ) );
+    HIP_TRY( s->hit.Allocate( entries * 16 ) );
+    HIP_TRY( s->rad.Allocate( capacity * 16 ) );
+    HIP_TRY( s->shadowO.Allocate( capacity * 16 ) );
+    HIP_TRY( s->shDir.Allocate( capacity * slots * 16 ) );
+    HIP_TRY( s->shEst.Allocate( capacity * slots * 16 ) );
     HIP_TRY( s->counts.Allocate( kCountsPerBounce * 4 * static_cast< size_t >( s->maxDepth > 0 ? s->maxDepth : 1 ) * units ) );
     HIP_TRY( s->queue0.Allocate( entries * 4 ) );
     HIP_TRY( s->queue1.Allocate( entries * 4 ) );
@@ -459,8 +462,11 @@ int EnsurePathBuffers( PtScene* s, uint64_t capacity )
     HIP_TRY( s->shadowRays.Allocate( entries * slots * 4 ) );
     if ( s->view.numSpheres ) HIP_TRY( s->sphereQueue.Allocate( entries * 4 ) );
     PathBuffers& p = s->paths;
-    p.rayO        = s->rayO.As< float4 >();
-    p.rayD        = s->rayD.As< float4 >();
+    p.rayO[0]     = s->rayO0.As< float4 >();
+    p.rayO[1]     = s->rayO1.As< float4 >();
+    p.rayD[0]     = s->rayD0.As< float4 >();
+    p.rayD[1]     = s->rayD1.As< float4 >();
+    p.shadowO     = s->shadowO.As< float4 >();
     p.thr[0]      = s->thr0.As< float4 >();
     p.thr[1]      = s->thr1.As< float4 >();
     p.rad         = s->rad.As< float4 >();

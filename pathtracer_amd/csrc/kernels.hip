@@ -483,8 +483,8 @@ __global__ __launch_bounds__( kBlock ) void RaygenKernel( CameraFrame cam, RngPa
         const float ju = r1 * ( 0.5f - -0.5f ) + -0.5f;
         f3 aa  = imagePlanePos + dU * ju + dV * jv;
         f3 dir = Normalize( aa - position );
-        pb.rayO[p]   = F4( position, 0.0f );
-        pb.rayD[p]   = F4( dir, 0.0f );
+        pb.rayO[0][p] = F4( position, 0.0f ); // at bounce 0 the queue is the identity: entry = path id
+        pb.rayD[0][p] = F4( dir, 0.0f );
         pb.thr[0][p] = make_float4( 1.0f, 1.0f, 1.0f, 0.0f );
     }
 }
@@ -615,7 +615,8 @@ constexpr int kTraverseBurst = PT_TRAVERSE_BURST;
 __global__ __launch_bounds__( kTraverseBlock ) PT_TRAVERSE_OCCUPANCY void ExtendKernel( SceneView sv, PathBuffers pb, int bounce, uint32_t numPaths, uint64_t* stats )
 {
     UnitStream stream{ pb.cursors + 2 * bounce, bounce == 0 ? nullptr : UnitCount( pb, bounce - 1, kCountNextPaths, 0 ), pb.units, kUnitPaths, numPaths };
-    const uint32_t* items = bounce == 0 ? nullptr : pb.queue[bounce & 1];
+    const float4* rayO = pb.rayO[bounce & 1];
+    const float4* rayD = pb.rayD[bounce & 1];
     const uint32_t end    = sv.numNodes;
     const SceneBuffers sb = MakeSceneBuffers( sv );
     __shared__ float4 topLds[kLdsTopNodes > 0 ? 2 * kLdsTopNodes : 1];
@@ -659,10 +660,9 @@ __global__ __launch_bounds__( kTraverseBlock ) PT_TRAVERSE_OCCUPANCY void Extend
                 const uint32_t rank = LanesBelow( mIdle );
                 if ( idle && p == kNoRay && rank < left )
                 {
-                    const uint32_t entry = stream.base + stream.taken + rank;
-                    p   = items ? items[entry] : entry;
-                    o   = F3( pb.rayO[p] );
-                    d   = F3( pb.rayD[p] );
+                    p   = stream.base + stream.taken + rank; // the ray's entry in the bounce's queue
+                    o   = F3( rayO[p] );
+                    d   = F3( rayD[p] );
                     inv = F3( 1.0f / d.x, 1.0f / d.y, 1.0f / d.z ); // bvh.cpp:235-236
                     nx = inv.x < 0; ny = inv.y < 0; nz = inv.z < 0;
                     h    = HitRecord{ FLT_MAX, 0.0f, 0.0f, -1 };     // scene.cpp:372
@@ -785,7 +785,7 @@ __global__ __launch_bounds__( kTraverseBlock ) PT_TRAVERSE_OCCUPANCY void Connec
                 {
                     rec = pb.shadowRays[stream.base + stream.taken + rank];
                     const float4 dir = pb.shDir[rec];
-                    o    = F3( pb.rayO[pb.shadowSlots == 1 ? rec : rec % capacity] ); // record index = slot * capacity + path
+                    o    = F3( pb.shadowO[pb.shadowSlots == 1 ? rec : rec % capacity] ); // record index = slot * capacity + path
                     d    = F3( dir );
                     tMax = dir.w;
                     inv  = F3( 1.0f / d.x, 1.0f / d.y, 1.0f / d.z ); // bvh.cpp:275-276
@@ -888,7 +888,7 @@ __global__ __launch_bounds__( kBlock ) void ShadeKernel( SceneView sv, RngParams
     if ( unit >= pb.units ) return;
     const uint32_t segment = unit * kUnitPaths;
     // entries of this unit: its sphere hits, all of its paths (bounce 0), or its paths still alive
-    const uint32_t* items = kSphereHits ? pb.sphereQueue + segment : bounce == 0 ? nullptr : pb.queue[cur] + segment;
+    const uint32_t* items = pb.sphereQueue + segment; // the sphere instance goes by this list of entries
     uint32_t limit;
     if ( kSphereHits )
         limit = *UnitCount( pb, bounce, kCountSphereHits, unit );
@@ -896,7 +896,6 @@ __global__ __launch_bounds__( kBlock ) void ShadeKernel( SceneView sv, RngParams
         limit = numPaths - segment < kUnitPaths ? numPaths - segment : kUnitPaths;
     else
         limit = *UnitCount( pb, bounce - 1, kCountNextPaths, unit );
-    uint32_t* outNext        = pb.queue[nxt] + segment;
     uint32_t* outShadowPaths = pb.shadowPaths + segment;
     uint32_t* outShadowRays  = pb.shadowRays + static_cast< size_t >( segment ) * pb.shadowSlots;
     // the sphere instance continues the segments the triangle instance has started
@@ -909,18 +908,19 @@ __global__ __launch_bounds__( kBlock ) void ShadeKernel( SceneView sv, RngParams
     for ( uint32_t j = LaneIndex(); Ballot( j < limit ) != 0; j += 64u )
     {
         bool lit = false, deferred = false, alive = false, anyShadow = false;
-        uint32_t p = 0, pixel = 0, sample = 0;
+        uint32_t p = 0, q = 0, pixel = 0, sample = 0; // path id, entry in this bounce's queue
         Surface sf{};
-        f3 T = F3( 0.0f, 0.0f, 0.0f );
+        f3 T = F3( 0.0f, 0.0f, 0.0f ), nextD = T, nextT = T;
 
         // hit attributes and material
         if ( j < limit )
         {
-            p = items ? items[j] : segment + j;
-            const float4 hr = pb.hit[p];
+            q = kSphereHits ? items[j] : segment + j;
+            p = bounce == 0 ? q : pb.queue[cur][q];
+            const float4 hr = pb.hit[q];
             const int prim  = __float_as_int( hr.w );
-            const f3 d = F3( pb.rayD[p] );
-            T    = F3( pb.thr[cur][p] );
+            const f3 d = F3( pb.rayD[cur][q] );
+            T    = F3( pb.thr[cur][q] );
             f3 L = F3( 0.0f, 0.0f, 0.0f ); // radiance so far: nothing at bounce 0; a hit at a later bounce does not touch it here
 
             if ( prim < 0 )
@@ -931,7 +931,7 @@ __global__ __launch_bounds__( kBlock ) void ShadeKernel( SceneView sv, RngParams
             }
             else
             {
-                const f3 o = F3( pb.rayO[p] );
+                const f3 o = F3( pb.rayO[cur][q] );
                 const float t = hr.x, u = hr.y, v = hr.z;
                 sf.position = o + d * t; // Ray::Evaluate
                 float tu, tv;
@@ -1090,16 +1090,28 @@ __global__ __launch_bounds__( kBlock ) void ShadeKernel( SceneView sv, RngParams
                 f3 Tn = T * ( ( sf.F * AbsDot( wi, sf.normal ) ) / pdf );
                 if ( !IsZero( Tn ) && bounce + 1 < maxDepth )
                 {
-                    alive          = true;
-                    pb.rayD[p]     = F4( wi, 0.0f );
-                    pb.thr[nxt][p] = F4( Tn, 0.0f );
+                    alive = true;
+                    nextD = wi;
+                    nextT = Tn;
                 }
             }
-            if ( alive || anyShadow ) pb.rayO[p] = F4( sf.position, 0.0f );
+            if ( anyShadow ) pb.shadowO[p] = F4( sf.position, 0.0f );
         }
-        SegmentAppend( alive, p, outNext, nNext );
-        SegmentAppend( anyShadow, p, outShadowPaths, nShadowPaths );
-        if constexpr ( !kSphereHits ) SegmentAppend( deferred, p, pb.sphereQueue + segment, nSpheres );
+        {
+            // the path's state for the next bounce goes where its queue entry goes
+            const unsigned long long mAlive = Ballot( alive );
+            if ( alive )
+            {
+                const uint32_t next = segment + nNext + LanesBelow( mAlive );
+                pb.queue[nxt][next] = p;
+                pb.rayO[nxt][next]  = F4( sf.position, 0.0f );
+                pb.rayD[nxt][next]  = F4( nextD, 0.0f );
+                pb.thr[nxt][next]   = F4( nextT, 0.0f );
+            }
+            nNext += static_cast< uint32_t >( __popcll( mAlive ) );
+        }
+        SegmentAppend( anyShadow, q, outShadowPaths, nShadowPaths );
+        if constexpr ( !kSphereHits ) SegmentAppend( deferred, q, pb.sphereQueue + segment, nSpheres );
     }
     if ( LaneIndex() == 0 )
     {
@@ -1123,7 +1135,7 @@ __global__ __launch_bounds__( kBlock ) void ResolveKernel( SceneView sv, PathBuf
     const uint32_t capacity = static_cast< uint32_t >( pb.capacity );
     for ( uint32_t j = LaneIndex(); j < limit; j += 64u )
     {
-        const uint32_t p = items[j];
+        const uint32_t q = items[j], p = bounce == 0 ? q : pb.queue[cur][q];
         f3 Ldirect = F3( 0.0f, 0.0f, 0.0f );
         uint32_t slot = 0;
         for ( uint32_t li = 0; li < sv.numLights; ++li )
@@ -1139,7 +1151,7 @@ __global__ __launch_bounds__( kBlock ) void ResolveKernel( SceneView sv, PathBuf
             }
             Ldirect = Ldirect + Ld / static_cast< float >( nSamples );
         }
-        const f3 T = F3( pb.thr[cur][p] );
+        const f3 T = F3( pb.thr[cur][q] );
         f3 L       = F3( pb.rad[p] );
         pb.rad[p]  = F4( L + T * Ldirect, 0.0f );
     }

@@ -94,19 +94,25 @@ struct RngParams
     int32_t tableDraws;
 };
 
+// Path state of one pass.  What a bounce reads - ray, throughput, closest hit - is indexed by queue position
+// (`entry` = unit * kUnitPaths + position in the unit's segment of the bounce's queue), so the arrays stay dense
+// as paths die; the bounce writes the state of the next one at the positions it appends to.  At bounce 0 the
+// queue is the identity (entry = path id).  What outlives a bounce or belongs to a path as a whole - radiance,
+// shadow records - is indexed by path id.
 struct PathBuffers
 {
-    float4* rayO;      // origin.xyz
-    float4* rayD;      // direction.xyz
-    float4* thr[2];    // throughput, double buffered per bounce
-    float4* rad;       // accumulated radiance of the path
-    float4* hit;       // t, u, v, prim (int bits; -1 = miss)
+    float4* rayO[2];   // [entry] origin.xyz, double buffered per bounce
+    float4* rayD[2];   // [entry] direction.xyz
+    float4* thr[2];    // [entry] throughput
+    float4* hit;       // [entry] t, u, v, prim (int bits; -1 = miss)
+    float4* rad;       // [path] accumulated radiance of the path
+    float4* shadowO;   // [path] origin of the path's shadow rays of this bounce
     float4* shDir;     // [slot * capacity + path]: wi.xyz, tMax (-1 = no ray, -2 = occluded)
     float4* shEst;     // [slot * capacity + path]: unoccluded contribution
-    uint32_t* queue[2];     // path ids entering a bounce, double buffered
-    uint32_t* shadowPaths;  // path ids that cast at least one shadow ray this bounce
-    uint32_t* shadowRays;   // shadow record indices (slot * capacity + path) to test for occlusion, capacity * slots entries
-    uint32_t* sphereQueue;  // path ids whose closest hit is a sphere, shaded by their own kernel instance
+    uint32_t* queue[2];     // [entry] path id, double buffered per bounce
+    uint32_t* shadowPaths;  // entries (of this bounce's queue) whose path cast at least one shadow ray
+    uint32_t* shadowRays;   // shadow record indices (slot * capacity + path) to test for occlusion, kUnitPaths * slots per unit
+    uint32_t* sphereQueue;  // entries whose closest hit is a sphere, shaded by their own kernel instance
     uint32_t* counts;       // [bounce][kCountsPerBounce][unit] queue segment lengths
     uint32_t* cursors;      // [bounce][2] next unit to hand out in ExtendKernel / ConnectKernel
     uint64_t capacity;      // paths in flight; capacity * shadow slots < 2^32
