@@ -281,7 +281,7 @@ int Upload( PtScene* s, const PtSceneDesc* d, const std::vector< uint32_t >& esc
     }
     HIP_TRY( s->nodes.Upload( nodes.data(), nodes.size() * 4 ) );
 
-    std::vector< float > prims( 12ull * P, 0.0f ), shade( 28ull * P, 0.0f );
+    std::vector< float > prims( 12ull * P, 0.0f ), shade( 32ull * P, 0.0f ); // 112 bytes of attributes in a 128-byte slot: one L2 line per record
     for ( uint64_t i = 0; i < P; ++i )
     {
         float* q = &prims[12 * i];
@@ -296,7 +296,7 @@ int Upload( PtScene* s, const PtSceneDesc* d, const std::vector< uint32_t >& esc
             std::memcpy( &q[3], &tag, 4 );
             q[4] = e1.x; q[5] = e1.y; q[6] = e1.z;
             q[8] = e2.x; q[9] = e2.y; q[10] = e2.z;
-            float* a = &shade[28 * i];
+            float* a = &shade[32 * i];
             const uint32_t idx[3] = { t.i0, t.i1, t.i2 };
             for ( int k = 0; k < 3; ++k )
             {

@@ -940,7 +940,7 @@ __global__ __launch_bounds__( kBlock ) void ShadeKernel( SceneView sv, RngParams
                 {
                     // Triangle::Intersect attribute interpolation (src/shapes.cpp:123-130).  The attribute record
                     // is fetched together with the tag; for a sphere primitive it is all zeros and unused.
-                    const float4* a = sv.triShade + 7 * static_cast< size_t >( prim );
+                    const float4* a = sv.triShade + 8 * static_cast< size_t >( prim );
                     const float4 a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3], a4 = a[4], a5 = a[5], a6 = a[6];
                     deferred = sv.numSpheres != 0 && __float_as_uint( sv.prims[3 * prim].w ) != kTagTriangle;
                     const f3 n0 = F3( a0.x, a0.y, a0.z ), n1 = F3( a0.w, a1.x, a1.y ), n2 = F3( a1.z, a1.w, a2.x );

@@ -6,7 +6,7 @@
 //              nodes are the top of the tree in breadth-first order, the rest follows in the reference's pre-order
 //   prims      3 x float4 per primitive (48 B): triangle {v0, tag 0} {v1 - v0} {v2 - v0};
 //              sphere {centre, tag 1} {radius, sphere index}
-//   triShade   7 x float4 per triangle primitive (112 B): n0 n1 n2 t0 t1 t2 uv0 uv1 uv2 material
+//   triShade   8 x float4 per triangle primitive (112 B used, 128 B apart = one L2 line): n0 n1 n2 t0 t1 t2 uv0 uv1 uv2 material
 //   spheres    6 x float4: world-to-local columns 0..3, {centre, radius}, {material}
 //   materials  2 x float4: {albedo, texture index} {Ke}
 //   lights     9 x float4, see DevLight
