@@ -281,10 +281,10 @@ int Upload( PtScene* s, const PtSceneDesc* d, const std::vector< uint32_t >& esc
     }
     HIP_TRY( s->nodes.Upload( nodes.data(), nodes.size() * 4 ) );
 
-    std::vector< float > prims( 12ull * P, 0.0f ), shade( 32ull * P, 0.0f ); // 112 bytes of attributes in a 128-byte slot: one L2 line per record
+    std::vector< float > prims( 16ull * P, 0.0f ), shade( 32ull * P, 0.0f ); // 112 bytes of attributes in a 128-byte slot: one L2 line per record
     for ( uint64_t i = 0; i < P; ++i )
     {
-        float* q = &prims[12 * i];
+        float* q = &prims[16 * i];
         if ( d->prims[i].type == PT_PRIM_TRIANGLE )
         {
             const PtTriangle& t = d->triangles[d->prims[i].index];

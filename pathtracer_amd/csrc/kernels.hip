@@ -90,7 +90,7 @@ struct SceneBuffers
 
 __device__ __forceinline__ SceneBuffers MakeSceneBuffers( const SceneView& sv )
 {
-    return SceneBuffers{ MakeBuffer( sv.nodes, sv.numNodes * 32u ), MakeBuffer( sv.prims, sv.numPrims * 48u ) };
+    return SceneBuffers{ MakeBuffer( sv.nodes, sv.numNodes * 32u ), MakeBuffer( sv.prims, sv.numPrims * 64u ) };
 }
 
 // std::cos / std::sin of a float in the reference: the host C library's sincosf, reproduced exactly
@@ -190,11 +190,11 @@ struct HitRecord
 };
 
 // One primitive test of a closest-hit leaf: Triangle::Intersect / Sphere::Intersect (src/shapes.cpp:117-123,
-// 52-61).  The 48-byte record is fetched whole before its tag is looked at (one memory round trip); the
+// 52-61).  The record (48 bytes of a 64-byte slot) is fetched whole before its tag is looked at (one memory round trip); the
 // triangle arithmetic runs on whatever was fetched and is discarded for a sphere record.
 __device__ __forceinline__ void ClosestPrimTest( const SceneView& sv, const SceneBuffers& sb, uint32_t prim, f3 o, f3 d, HitRecord& h, bool* wasSphere )
 {
-    const float4 q0 = Load16( sb.prims, 48u * prim ), q1 = Load16( sb.prims, 48u * prim + 16u ), q2 = Load16( sb.prims, 48u * prim + 32u );
+    const float4 q0 = Load16( sb.prims, 64u * prim ), q1 = Load16( sb.prims, 64u * prim + 16u ), q2 = Load16( sb.prims, 64u * prim + 32u );
     float t = 0.0f, u = 0.0f, v = 0.0f;
     bool hit   = RayTriangle( o, d, F3( q0 ), F3( q1 ), F3( q2 ), h.t, &t, &u, &v );
     *wasSphere = __float_as_uint( q0.w ) != kTagTriangle;
@@ -214,7 +214,7 @@ __device__ __forceinline__ void ClosestPrimTest( const SceneView& sv, const Scen
 // One primitive test of an any-hit leaf: TestIfHit (src/shapes.cpp:78-82, 136-141), spheres in world space.
 __device__ __forceinline__ bool AnyPrimTest( const SceneBuffers& sb, uint32_t prim, f3 o, f3 d, float tMax, bool* wasSphere )
 {
-    const float4 q0 = Load16( sb.prims, 48u * prim ), q1 = Load16( sb.prims, 48u * prim + 16u ), q2 = Load16( sb.prims, 48u * prim + 32u );
+    const float4 q0 = Load16( sb.prims, 64u * prim ), q1 = Load16( sb.prims, 64u * prim + 16u ), q2 = Load16( sb.prims, 64u * prim + 32u );
     float t = 0.0f, u, v;
     bool hit   = RayTriangle( o, d, F3( q0 ), F3( q1 ), F3( q2 ), tMax, &t, &u, &v );
     *wasSphere = __float_as_uint( q0.w ) != kTagTriangle;
@@ -942,7 +942,7 @@ __global__ __launch_bounds__( kBlock ) void ShadeKernel( SceneView sv, RngParams
                     // is fetched together with the tag; for a sphere primitive it is all zeros and unused.
                     const float4* a = sv.triShade + 8 * static_cast< size_t >( prim );
                     const float4 a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3], a4 = a[4], a5 = a[5], a6 = a[6];
-                    deferred = sv.numSpheres != 0 && __float_as_uint( sv.prims[3 * prim].w ) != kTagTriangle;
+                    deferred = sv.numSpheres != 0 && __float_as_uint( sv.prims[4 * prim].w ) != kTagTriangle;
                     const f3 n0 = F3( a0.x, a0.y, a0.z ), n1 = F3( a0.w, a1.x, a1.y ), n2 = F3( a1.z, a1.w, a2.x );
                     const f3 t0 = F3( a2.y, a2.z, a2.w ), t1 = F3( a3.x, a3.y, a3.z ), t2 = F3( a3.w, a4.x, a4.y );
                     const float w = 1 - u - v;
@@ -957,7 +957,7 @@ __global__ __launch_bounds__( kBlock ) void ShadeKernel( SceneView sv, RngParams
                 {
                     // Sphere::Intersect (src/shapes.cpp:61-73).  atan2 / sin / cos are the double functions in
                     // the reference's build, acosf the float one.
-                    const float4 q0 = sv.prims[3 * prim], q1 = sv.prims[3 * prim + 1];
+                    const float4 q0 = sv.prims[4 * prim], q1 = sv.prims[4 * prim + 1];
                     const float4* s = sv.spheres + 6 * __float_as_uint( q1.y );
                     const float4 c0 = s[0], c1 = s[1], c2 = s[2], c3 = s[3];
                     sf.normal = Normalize( sf.position - F3( q0 ) );

@@ -4,7 +4,7 @@
 //   nodes      2 x float4 per node (32 B): {lo.x, lo.y, hi.x, hi.y} {lo.z, hi.z, link, word}; link = node to go to after
 //              this node's subtree (top bit: leaf), word = leaf descriptor or first child.  The first numTopNodes
 //              nodes are the top of the tree in breadth-first order, the rest follows in the reference's pre-order
-//   prims      3 x float4 per primitive (48 B): triangle {v0, tag 0} {v1 - v0} {v2 - v0};
+//   prims      4 x float4 per primitive (48 B used, 64 B apart = one cache line): triangle {v0, tag 0} {v1 - v0} {v2 - v0};
 //              sphere {centre, tag 1} {radius, sphere index}
 //   triShade   8 x float4 per triangle primitive (112 B used, 128 B apart = one L2 line): n0 n1 n2 t0 t1 t2 uv0 uv1 uv2 material
 //   spheres    6 x float4: world-to-local columns 0..3, {centre, radius}, {material}
@@ -26,7 +26,7 @@ constexpr uint32_t kLeafFirstMask = 0x0FFFFFFFu; // leaf word: low 28 bits first
 constexpr int kMaxLeafShapes     = 16;
 // nodes and primitive records are read through 32-bit-offset buffer descriptors: each array stays under 4 GiB
 constexpr uint32_t kMaxNodes = 0x7FFFFFFFu / 32u - 1u;
-constexpr uint32_t kMaxPrims = 0xFFFFFFFFu / 48u - 1u;
+constexpr uint32_t kMaxPrims = 0xFFFFFFFFu / 64u - 1u;
 constexpr uint32_t kTagTriangle = 0, kTagSphere = 1;
 
 struct DevLight // 144 bytes
