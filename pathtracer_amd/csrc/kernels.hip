@@ -627,7 +627,7 @@ __global__ __launch_bounds__( kTraverseBlock ) PT_TRAVERSE_OCCUPANCY void Extend
         __syncthreads();
     }
     // node: the node to visit next (or, while a leaf is pending, the node to go to after it); leaf: pending leaf word
-    uint32_t p = kNoRay, node = end, leaf = kInnerNode;
+    uint32_t entry = kNoRay, node = end, leaf = kInnerNode; // entry: the lane's ray, as its position in the bounce's queue
     f3 o = F3( 0.0f, 0.0f, 0.0f ), d = o, inv = o;
     bool nx = false, ny = false, nz = false;
     HitRecord h{ FLT_MAX, 0.0f, 0.0f, -1 };
@@ -640,16 +640,16 @@ __global__ __launch_bounds__( kTraverseBlock ) PT_TRAVERSE_OCCUPANCY void Extend
         // masks built from single compares (a ballot of a compound predicate costs two more vector instructions)
         const unsigned long long mLeaf = Ballot( atLeaf ), mEnd = Ballot( node == end );
         const unsigned long long mTrav = ~mEnd & ~mLeaf;
-        const unsigned long long mRay  = mEnd & ~mLeaf & ( stream.ended ? Ballot( p != kNoRay ) : ~0ull );
+        const unsigned long long mRay  = mEnd & ~mLeaf & ( stream.ended ? Ballot( entry != kNoRay ) : ~0ull );
         if ( ( mLeaf | mTrav | mRay ) == 0 ) break;
 
         if ( mRay && ( __popcll( mRay ) >= kExtendRefillLanes || ( mTrav | mLeaf ) == 0 ) )
         {
-            if ( idle && p != kNoRay ) pb.hit[p] = make_float4( h.t, h.u, h.v, __int_as_float( h.prim ) );
-            if ( idle ) p = kNoRay;
+            if ( idle && entry != kNoRay ) pb.hit[entry] = make_float4( h.t, h.u, h.v, __int_as_float( h.prim ) );
+            if ( idle ) entry = kNoRay;
             while ( !stream.ended )
             {
-                const unsigned long long mIdle = Ballot( idle && p == kNoRay );
+                const unsigned long long mIdle = Ballot( idle && entry == kNoRay );
                 if ( mIdle == 0 ) break;
                 if ( stream.taken == stream.count )
                 {
@@ -658,11 +658,11 @@ __global__ __launch_bounds__( kTraverseBlock ) PT_TRAVERSE_OCCUPANCY void Extend
                 }
                 const uint32_t left = stream.count - stream.taken, asking = static_cast< uint32_t >( __popcll( mIdle ) );
                 const uint32_t rank = LanesBelow( mIdle );
-                if ( idle && p == kNoRay && rank < left )
+                if ( idle && entry == kNoRay && rank < left )
                 {
-                    p   = stream.base + stream.taken + rank; // the ray's entry in the bounce's queue
-                    o   = F3( rayO[p] );
-                    d   = F3( rayD[p] );
+                    entry = stream.base + stream.taken + rank;
+                    o   = F3( rayO[entry] );
+                    d   = F3( rayD[entry] );
                     inv = F3( 1.0f / d.x, 1.0f / d.y, 1.0f / d.z ); // bvh.cpp:235-236
                     nx = inv.x < 0; ny = inv.y < 0; nz = inv.z < 0;
                     h    = HitRecord{ FLT_MAX, 0.0f, 0.0f, -1 };     // scene.cpp:372
