@@ -452,9 +452,9 @@ int EnsurePathBuffers( PtScene* s, uint64_t capacity )
     HIP_TRY( s->thr1.Allocate( entries * 16 ) );
     HIP_TRY( s->hit.Allocate( entries * 16 ) );
     HIP_TRY( s->rad.Allocate( capacity * 16 ) );
-    HIP_TRY( s->shadowO.Allocate( capacity * 16 ) );
-    HIP_TRY( s->shDir.Allocate( capacity * slots * 16 ) );
-    HIP_TRY( s->shEst.Allocate( capacity * slots * 16 ) );
+    HIP_TRY( s->shadowO.Allocate( entries * 16 ) );
+    HIP_TRY( s->shDir.Allocate( entries * slots * 16 ) );
+    HIP_TRY( s->shEst.Allocate( entries * slots * 16 ) );
     HIP_TRY( s->counts.Allocate( kCountsPerBounce * 4 * static_cast< size_t >( s->maxDepth > 0 ? s->maxDepth : 1 ) * units ) );
     HIP_TRY( s->queue0.Allocate( entries * 4 ) );
     HIP_TRY( s->queue1.Allocate( entries * 4 ) );
@@ -631,13 +631,13 @@ int pt_render( PtScene* s, const PtRenderParams* p )
     {
         const uint64_t slots = s->view.shadowSlots > 0 ? s->view.shadowSlots : 1;
         uint64_t maxPaths = std::min< uint64_t >( 64ull << 20, ( 24ull << 30 ) / s->bytesPerPathFixed );
-        maxPaths = std::min< uint64_t >( maxPaths, 0xfffffffeull / slots );
+        maxPaths = std::min< uint64_t >( maxPaths, 0xfffffffeull / slots - kUnitPaths );
         perPass = std::max< uint64_t >( 1, maxPaths / pixels );
     }
     if ( perPass > static_cast< uint64_t >( totalSamples ) ) perPass = totalSamples > 0 ? totalSamples : 1;
     {
         const uint64_t slots = s->view.shadowSlots > 0 ? s->view.shadowSlots : 1;
-        if ( perPass * pixels * slots > 0xfffffffeull )
+        if ( ( perPass * pixels + kUnitPaths ) * slots > 0xfffffffeull )
             return Fail( PT_ERR_INVALID_ARG, "pt_render: %llu samples per pass of %llu pixels with %llu shadow rays per hit exceeds 2^32 shadow records",
                          (unsigned long long)perPass, (unsigned long long)pixels, (unsigned long long)slots );
     }

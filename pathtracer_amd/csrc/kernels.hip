@@ -741,7 +741,7 @@ __global__ __launch_bounds__( kTraverseBlock ) PT_TRAVERSE_OCCUPANCY void Connec
 {
     UnitStream stream{ pb.cursors + 2 * bounce + 1, UnitCount( pb, bounce, kCountShadowRays, 0 ), pb.units, kUnitPaths * pb.shadowSlots, 0u };
     const uint32_t end      = sv.numNodes;
-    const uint32_t capacity = static_cast< uint32_t >( pb.capacity );
+    const uint32_t entries  = pb.units * kUnitPaths;
     const SceneBuffers sb   = MakeSceneBuffers( sv );
     __shared__ float4 topLds[kLdsTopNodes > 0 ? 2 * kLdsTopNodes : 1];
     const uint32_t topCount = kLdsTopNodes < sv.numTopNodes ? kLdsTopNodes : sv.numTopNodes;
@@ -785,7 +785,7 @@ __global__ __launch_bounds__( kTraverseBlock ) PT_TRAVERSE_OCCUPANCY void Connec
                 {
                     rec = pb.shadowRays[stream.base + stream.taken + rank];
                     const float4 dir = pb.shDir[rec];
-                    o    = F3( pb.shadowO[pb.shadowSlots == 1 ? rec : rec % capacity] ); // record index = slot * capacity + path
+                    o    = F3( pb.shadowO[pb.shadowSlots == 1 ? rec : rec % entries] ); // record index = slot * entries + entry
                     d    = F3( dir );
                     tMax = dir.w;
                     inv  = F3( 1.0f / d.x, 1.0f / d.y, 1.0f / d.z ); // bvh.cpp:275-276
@@ -1006,7 +1006,7 @@ __global__ __launch_bounds__( kBlock ) void ShadeKernel( SceneView sv, RngParams
             for ( int smp = 0; smp < l.nSamples; ++smp, ++slot )
             {
                 bool skip = true;
-                const uint32_t rec = slot * static_cast< uint32_t >( pb.capacity ) + p;
+                const uint32_t rec = slot * ( pb.units * kUnitPaths ) + q;
                 if ( lit )
                 {
                     skip = false;
@@ -1095,7 +1095,7 @@ __global__ __launch_bounds__( kBlock ) void ShadeKernel( SceneView sv, RngParams
                     nextT = Tn;
                 }
             }
-            if ( anyShadow ) pb.shadowO[p] = F4( sf.position, 0.0f );
+            if ( anyShadow ) pb.shadowO[q] = F4( sf.position, 0.0f );
         }
         {
             // the path's state for the next bounce goes where its queue entry goes
@@ -1132,7 +1132,7 @@ __global__ __launch_bounds__( kBlock ) void ResolveKernel( SceneView sv, PathBuf
     const uint32_t* items = pb.shadowPaths + unit * kUnitPaths;
     const uint32_t limit  = *UnitCount( pb, bounce, kCountShadowPaths, unit );
     const int cur = bounce & 1;
-    const uint32_t capacity = static_cast< uint32_t >( pb.capacity );
+    const uint32_t entries = pb.units * kUnitPaths;
     for ( uint32_t j = LaneIndex(); j < limit; j += 64u )
     {
         const uint32_t q = items[j], p = bounce == 0 ? q : pb.queue[cur][q];
@@ -1144,7 +1144,7 @@ __global__ __launch_bounds__( kBlock ) void ResolveKernel( SceneView sv, PathBuf
             f3 Ld = F3( 0.0f, 0.0f, 0.0f );
             for ( int smp = 0; smp < nSamples; ++smp, ++slot )
             {
-                const uint32_t rec = slot * capacity + p;
+                const uint32_t rec = slot * entries + q;
                 const float tMax   = reinterpret_cast< const float* >( pb.shDir )[4ull * rec + 3];
                 if ( tMax < 0.0f ) continue; // -1: no ray was cast, -2: occluded
                 Ld = Ld + F3( pb.shEst[rec] );

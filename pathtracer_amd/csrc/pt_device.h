@@ -97,8 +97,8 @@ struct RngParams
 // Path state of one pass.  What a bounce reads - ray, throughput, closest hit - is indexed by queue position
 // (`entry` = unit * kUnitPaths + position in the unit's segment of the bounce's queue), so the arrays stay dense
 // as paths die; the bounce writes the state of the next one at the positions it appends to.  At bounce 0 the
-// queue is the identity (entry = path id).  What outlives a bounce or belongs to a path as a whole - radiance,
-// shadow records - is indexed by path id.
+// queue is the identity (entry = path id).  Shadow records belong to the bounce that casts them and are indexed by
+// its entries too; only the radiance, which outlives the bounces, is indexed by path id.
 struct PathBuffers
 {
     float4* rayO[2];   // [entry] origin.xyz, double buffered per bounce
@@ -106,16 +106,16 @@ struct PathBuffers
     float4* thr[2];    // [entry] throughput
     float4* hit;       // [entry] t, u, v, prim (int bits; -1 = miss)
     float4* rad;       // [path] accumulated radiance of the path
-    float4* shadowO;   // [path] origin of the path's shadow rays of this bounce
-    float4* shDir;     // [slot * capacity + path]: wi.xyz, tMax (-1 = no ray, -2 = occluded)
-    float4* shEst;     // [slot * capacity + path]: unoccluded contribution
+    float4* shadowO;   // [entry] origin of the path's shadow rays of this bounce
+    float4* shDir;     // [slot * entries + entry]: wi.xyz, tMax (-1 = no ray, -2 = occluded); entries = units * kUnitPaths
+    float4* shEst;     // [slot * entries + entry]: unoccluded contribution
     uint32_t* queue[2];     // [entry] path id, double buffered per bounce
     uint32_t* shadowPaths;  // entries (of this bounce's queue) whose path cast at least one shadow ray
-    uint32_t* shadowRays;   // shadow record indices (slot * capacity + path) to test for occlusion, kUnitPaths * slots per unit
+    uint32_t* shadowRays;   // shadow record indices (slot * entries + entry) to test for occlusion, kUnitPaths * slots per unit
     uint32_t* sphereQueue;  // entries whose closest hit is a sphere, shaded by their own kernel instance
     uint32_t* counts;       // [bounce][kCountsPerBounce][unit] queue segment lengths
     uint32_t* cursors;      // [bounce][2] next unit to hand out in ExtendKernel / ConnectKernel
-    uint64_t capacity;      // paths in flight; capacity * shadow slots < 2^32
+    uint64_t capacity;      // paths in flight; units * kUnitPaths * shadow slots < 2^32
     uint32_t units;         // units of kUnitPaths consecutive path ids in this pass
     uint32_t shadowSlots;   // shadow records per path, at least 1
 };
