@@ -429,14 +429,43 @@ __device__ __forceinline__ f3 Environment( const SceneView& sv, f3 v )
 
 constexpr int kBlock = 256;
 
-// Path id -> pixel.  Path ids run sample-major (id = local sample * pixels + slot) and a slot is a pixel in
-// tile order: the part of the image that 16 x 16 tiles cover, tile by tile and row-major inside a tile, then the
-// columns right of it, then the rows below.  256 consecutive path ids - one unit of work, four wave loads - are
-// one tile, so the rays a wave traces together start from neighbouring surface points.
+// Path id -> (sample, pixel).  A slot is a pixel in tile order: the part of the image that 16 x 16 tiles cover,
+// tile by tile and row-major inside a tile, then the columns right of it, then the rows below.  Path ids run tile
+// by tile, and for a tile sample by sample: 256 consecutive ids - one unit of work, four wave loads - are one
+// sample of one tile, and the units the GPU works on at any moment are all the samples of a few tiles, so the rays
+// traced together start from neighbouring surface points.  The pixels outside the tiled area follow, sample-major.
 struct PixelOrder
 {
     uint32_t width, height;
 };
+
+struct PathOrder
+{
+    uint32_t width, height, samples; // samples of every pixel in this pass
+};
+
+__device__ __forceinline__ void PathToSampleSlot( PathOrder po, uint32_t path, uint32_t* sample, uint32_t* slot )
+{
+    const uint32_t tiled = ( po.width & ~15u ) * ( po.height & ~15u ), tiledPaths = tiled * po.samples;
+    if ( path < tiledPaths )
+    {
+        const uint32_t unit = path >> 8;
+        *sample = unit % po.samples;
+        *slot   = ( unit / po.samples ) * 256u + ( path & 255u );
+        return;
+    }
+    const uint32_t rest = po.width * po.height - tiled;
+    path -= tiledPaths;
+    *sample = path / rest;
+    *slot   = tiled + path % rest;
+}
+
+__device__ __forceinline__ uint32_t SampleSlotToPath( PathOrder po, uint32_t sample, uint32_t slot )
+{
+    const uint32_t tiled = ( po.width & ~15u ) * ( po.height & ~15u );
+    if ( slot < tiled ) return ( ( slot >> 8 ) * po.samples + sample ) * 256u + ( slot & 255u );
+    return tiled * po.samples + sample * ( po.width * po.height - tiled ) + ( slot - tiled );
+}
 
 __device__ __forceinline__ void SlotToPixel( PixelOrder po, uint32_t slot, uint32_t* row, uint32_t* col )
 {
@@ -462,17 +491,17 @@ __device__ __forceinline__ void SlotToPixel( PixelOrder po, uint32_t slot, uint3
 }
 
 // Primary rays: pixel position, jitter, normalised direction (src/path_tracer.cpp:183-189,
-// src/anti_aliasing.cpp:89-92).  Path id = local sample * pixels + pixel.
+// src/anti_aliasing.cpp:89-92).
 __global__ __launch_bounds__( kBlock ) void RaygenKernel( CameraFrame cam, RngParams rng, PathBuffers pb, uint32_t width,
                                                          uint32_t height, uint32_t sampleBegin, uint32_t numPaths )
 {
     const uint32_t numPixels = width * height;
     for ( uint32_t p = blockIdx.x * kBlock + threadIdx.x; p < numPaths; p += gridDim.x * kBlock )
     {
-        const uint32_t sample = sampleBegin + p / numPixels;
-        uint32_t row, col;
-        SlotToPixel( PixelOrder{ width, height }, p % numPixels, &row, &col );
-        const uint32_t pixel = row * width + col;
+        uint32_t local, slot, row, col;
+        PathToSampleSlot( PathOrder{ width, height, numPaths / numPixels }, p, &local, &slot );
+        SlotToPixel( PixelOrder{ width, height }, slot, &row, &col );
+        const uint32_t pixel = row * width + col, sample = sampleBegin + local;
         const f3 position = F3( cam.position ), UL = F3( cam.UL ), dU = F3( cam.dU ), dV = F3( cam.dV );
         f3 imagePlanePos = UL + dV * static_cast< float >( row ) + dU * static_cast< float >( col );
         // RandFloat( -0.5f, 0.5f ) = Rand() * ( h - l ) + l (src/utils/random.cpp:18-21).  The reference as
@@ -988,10 +1017,11 @@ __global__ __launch_bounds__( kBlock ) void ShadeKernel( SceneView sv, RngParams
                     const int tex = __float_as_int( m0.w );
                     if ( tex >= 0 ) Kd = Kd * TextureFetch( sv, tex, tu, tv );
                     sf.F   = Kd / kPi; // BRDF::F (src/resource/material.cpp:15-18)
-                    uint32_t row, col;
-                    SlotToPixel( PixelOrder{ width, height }, p % numPixels, &row, &col );
+                    uint32_t local, slot, row, col;
+                    PathToSampleSlot( PathOrder{ width, height, numPaths / numPixels }, p, &local, &slot );
+                    SlotToPixel( PixelOrder{ width, height }, slot, &row, &col );
                     pixel  = row * width + col;
-                    sample = sampleBegin + p / numPixels;
+                    sample = sampleBegin + local;
                 }
             }
         }
@@ -1169,7 +1199,7 @@ __global__ __launch_bounds__( kBlock ) void FilmKernel( PathBuffers pb, float4* 
         float4 f = film[pixel];
         for ( uint32_t s = 0; s < samplesInPass; ++s )
         {
-            const float4 L = pb.rad[static_cast< size_t >( s ) * numPixels + slot];
+            const float4 L = pb.rad[SampleSlotToPath( PathOrder{ width, height, samplesInPass }, s, slot )];
             f.x += L.x;
             f.y += L.y;
             f.z += L.z;
