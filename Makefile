@@ -15,7 +15,7 @@ HOST_LIB_SRC := $(filter-out pathtracer_amd/host/main.cpp,$(HOST_SRC))
 HOST_HDR := $(wildcard pathtracer_amd/host/*.hpp) $(wildcard include/*.h)
 
 # -ffp-contract=off: host float math must round like the reference's (x86-64, no FMA contraction)
-HOST_FLAGS := -std=c++17 -O2 -fPIC -ffp-contract=off -Wall -Wno-unused-function $(INC) -Ipathtracer_amd/host
+HOST_FLAGS := -std=c++17 -O2 -fPIC -pthread -ffp-contract=off -Wall -Wno-unused-function $(INC) -Ipathtracer_amd/host
 
 HIP_SRC  := $(wildcard pathtracer_amd/csrc/*.hip)
 HIP_HDR  := $(wildcard pathtracer_amd/csrc/*.h) $(wildcard pathtracer_amd/csrc/*.hpp) $(wildcard include/*.h)

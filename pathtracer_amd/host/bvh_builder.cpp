@@ -1,6 +1,9 @@
 #include "bvh_builder.hpp"
 #include <algorithm>
+#include <atomic>
+#include <cstdlib>
 #include <stdexcept>
+#include <thread>
 
 namespace pth
 {
@@ -41,15 +44,21 @@ namespace
     constexpr int kBuckets        = 12; // src/bvh.cpp:102
     constexpr int kSmallRangeSize = 4;  // src/bvh.cpp:95,150
 
-    // Emits the subtree over items[start, end) straight into the pre-order array: a node's slot is the
-    // array size on entry, its first child follows immediately and the second child's slot is the array
-    // size once the first subtree is complete - the layout FlattenBVHBuild produces (src/bvh.cpp:180-202)
-    // without the intermediate pointer tree.
+    // Ranges of at least this many shapes hand their first half to another thread while one is free.
+    constexpr int kParallelRange = 1 << 15;
+
+    // Emits the subtree over items[start, end) straight into the pre-order array - the layout
+    // FlattenBVHBuild produces (src/bvh.cpp:180-202) without the intermediate pointer tree.  Every leaf holds
+    // exactly one shape, so the subtree over n shapes has 2n - 1 nodes: a node's slot is known before its
+    // subtree is built, its first child takes the next slot and its second child the slot 2 * (cutoff - start)
+    // further on; leaf i of the tree is items[i].  That makes the two halves of a range independent, and they
+    // are built on different threads with the same result as the sequential recursion.
     struct Builder
     {
         std::vector< Item >& items;
         SplitMethod method;
         BvhResult& out;
+        std::atomic< int > freeThreads;
 
         int BucketOf( const Aabb& centroidBox, const Item& it, int dim ) const
         {
@@ -110,11 +119,8 @@ namespace
                                    [&]( const Item& it ) { return BucketOf( centroidBox, it, dim ) <= minBucket; } );
         }
 
-        void Emit( int start, int end )
+        void Emit( int start, int end, size_t slot )
         {
-            const size_t slot = out.nodes.size();
-            out.nodes.emplace_back();
-
             Aabb box;
             for ( int i = start; i < end; ++i ) box.Union( items[i].box );
 
@@ -128,10 +134,10 @@ namespace
             const int count = end - start;
             if ( count == 1 ) // src/bvh.cpp:47-56
             {
-                node.offset     = static_cast< int32_t >( out.order.size() );
+                node.offset     = start;
                 node.num_shapes = 1;
-                out.order.push_back( items[start].shape );
-                out.nodes[slot] = node;
+                out.order[start] = items[start].shape;
+                out.nodes[slot]  = node;
                 return;
             }
 
@@ -170,10 +176,20 @@ namespace
                 cutoff = ( start + end ) / 2;
             }
 
-            Emit( start, cutoff );
-            node.offset = static_cast< int32_t >( out.nodes.size() );
-            Emit( cutoff, end );
-            out.nodes[slot] = node;
+            const size_t second = slot + 2 * static_cast< size_t >( cutoff - start );
+            node.offset         = static_cast< int32_t >( second );
+            out.nodes[slot]     = node;
+            if ( count >= kParallelRange && freeThreads.fetch_sub( 1 ) > 0 )
+            {
+                std::thread firstHalf( [=]() { Emit( start, cutoff, slot + 1 ); } );
+                Emit( cutoff, end, second );
+                firstHalf.join();
+                freeThreads.fetch_add( 1 );
+                return;
+            }
+            if ( count >= kParallelRange ) freeThreads.fetch_add( 1 );
+            Emit( start, cutoff, slot + 1 );
+            Emit( cutoff, end, second );
         }
     };
 
@@ -193,10 +209,12 @@ BvhResult BuildBvh( const std::vector< Aabb >& bounds, SplitMethod method )
     }
 
     BvhResult out;
-    out.nodes.reserve( 2 * bounds.size() );
-    out.order.reserve( bounds.size() );
-    Builder b{ items, method, out };
-    b.Emit( 0, static_cast< int >( bounds.size() ) );
+    out.nodes.resize( 2 * bounds.size() - 1 );
+    out.order.resize( bounds.size() );
+    int threads = static_cast< int >( std::min( 16u, std::max( 1u, std::thread::hardware_concurrency() ) ) );
+    if ( const char* env = std::getenv( "PT_BUILD_THREADS" ) ) threads = std::max( 1, std::atoi( env ) );
+    Builder b{ items, method, out, { threads - 1 } };
+    b.Emit( 0, static_cast< int >( bounds.size() ), 0 );
     return out;
 }
 

@@ -140,3 +140,18 @@ def test_soup_with_environment_map():
             lin, stats = check_against_oracle(dev, checker.OracleScene(desc), 4, 8, "soup 2M 512^2 4 spp", lights=False)
             assert stats.shaded_hits > 0 and lin.mean() > 0.0
             check_split_is_bit_identical(dev, 6, 2, seed=1)
+
+
+@pytest.mark.timeout(600)
+def test_soup_20m_triangles_4k():
+    """The divergence stress configuration at its full size: 20 M random triangles (40 M nodes, 1.28 GB), 1024^2
+    cube map, 3840x2160, depth 5.  One sample per pixel against the checker, then a two-sample render split in
+    two calls."""
+    with host.HostScene.soup(seed=3, triangles=20_000_000, edge=0.01, skybox_size=1024) as hs:
+        desc = hs.desc()
+        assert (desc.image_width, desc.image_height, desc.max_depth) == (3840, 2160, 5)
+        assert desc.num_nodes == 2 * 20_000_000 - 1
+        with api.DeviceScene(desc) as dev:
+            lin, stats = check_against_oracle(dev, checker.OracleScene(desc), 1, 21, "soup 20M 4K 1 spp", lights=False)
+            assert stats.shaded_hits > 0 and lin.mean() > 0.0
+            check_split_is_bit_identical(dev, 2, 1, seed=2)
