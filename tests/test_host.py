@@ -42,6 +42,23 @@ def test_bvh_degenerate_centroids_terminate():
     assert len(nodes) == 17 and sorted(order.tolist()) == list(range(9))
 
 
+@pytest.mark.parametrize("method", [abi.PTH_SPLIT_SAH, abi.PTH_SPLIT_MIDDLE, abi.PTH_SPLIT_EQUAL_COUNTS])
+def test_bvh_threaded_build_equals_sequential_build(method, monkeypatch):
+    """Ranges of 32 Ki shapes and more build their halves on separate threads; the arrays are those of the
+    sequential recursion (the one pinned against the reference's BVH::Build above)."""
+    rng = np.random.default_rng(5)
+    n = 300_000
+    c = rng.uniform(-1, 1, (n, 3)).astype(np.float32)
+    e = rng.uniform(0, 0.02, (n, 3)).astype(np.float32)
+    boxes = np.concatenate([c - e, c + e], axis=1)
+    monkeypatch.setenv("PT_BUILD_THREADS", "1")
+    nodes1, order1 = host.build_bvh(boxes, method)
+    monkeypatch.setenv("PT_BUILD_THREADS", "7")
+    nodes7, order7 = host.build_bvh(boxes, method)
+    assert len(nodes1) == 2 * n - 1
+    assert nodes1.tobytes() == nodes7.tobytes() and np.array_equal(order1, order7)
+
+
 def write_tga(path, rgba):
     h, w, _ = rgba.shape
     hdr = bytearray(18)
