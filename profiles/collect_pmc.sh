@@ -1,17 +1,26 @@
 #!/bin/bash
 # Profiles bench.py on the GPU box: one rocprofv3 kernel trace with statistics, then one run per PMC pass
 # (counters only, never combined with a trace).  usage, from the repository root:  profiles/collect_pmc.sh <tag>
+# With more arguments, "<tag> script.py args..." profiles that python script (path relative to the repository
+# root) instead of bench.py, with the same arguments in every pass.
 # Output: gpurun_out/<tag>/{trace,sq,mem,fetch,write}/ and gpurun_out/<tag>/pmc_summary.{json,txt}
 set -u
 TAG=${1:-pmc}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH=$GRAFT_REPO_ROOT/bench.py
-timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $BENCH --steps 4 --warmup 1 --cpu-baseline-spp 0 > $OUT/trace.log 2>&1 || exit 1
+if [ $# -ge 2 ]; then
+  shift
+  PROG=$GRAFT_REPO_ROOT/$1; shift
+  TRACE_ARGS=("$@"); PASS_ARGS=("$@")
+else
+  PROG=$GRAFT_REPO_ROOT/bench.py
+  TRACE_ARGS=(--steps 4 --warmup 1 --cpu-baseline-spp 0); PASS_ARGS=(--steps 1 --warmup 0 --cpu-baseline-spp 0)
+fi
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $PROG "${TRACE_ARGS[@]}" > $OUT/trace.log 2>&1 || exit 1
 run_pass() {
   name=$1; shift
-  timeout -s KILL 180 rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- python3 $BENCH --steps 1 --warmup 0 --cpu-baseline-spp 0 > $OUT/$name.log 2>&1 || return 1
+  timeout -s KILL 180 rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- python3 $PROG "${PASS_ARGS[@]}" > $OUT/$name.log 2>&1 || return 1
 }
 run_pass sq SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VMEM_RD && \
 run_pass mem TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCC_REQ_sum TCC_MISS_sum GRBM_GUI_ACTIVE && \

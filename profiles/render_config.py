@@ -1,0 +1,41 @@
+"""Renders one of the procedural configurations once, for the profiler.
+usage: python3 profiles/render_config.py soup|knot|atrium [--triangles N] [--spp N] [--width W --height H] [--depth D]"""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from pathtracer_amd import api, host  # noqa: E402
+
+p = argparse.ArgumentParser()
+p.add_argument("scene", choices=["soup", "knot", "atrium"])
+p.add_argument("--triangles", type=int, default=0)
+p.add_argument("--spp", type=int, default=4)
+p.add_argument("--width", type=int, default=0)
+p.add_argument("--height", type=int, default=0)
+p.add_argument("--depth", type=int, default=-1)
+a = p.parse_args()
+
+if a.scene == "soup":
+    hs = host.HostScene.soup(seed=3, triangles=a.triangles or 20_000_000, edge=0.01, skybox_size=1024)
+elif a.scene == "knot":
+    hs = host.HostScene.knot(seed=2, triangles=a.triangles or 871414)
+else:
+    hs = host.HostScene.atrium(seed=1, triangles=a.triangles or 262267, texture_size=1024)
+with hs:
+    if a.width and a.height:
+        hs.set_image(a.width, a.height, a.width / a.height)
+    if a.depth >= 0:
+        hs.set_max_depth(a.depth)
+    with api.DeviceScene(hs.desc()) as dev:
+        dev.render(a.spp, seed=0)
+        _, _, st = dev.readback()
+        rays = st.rays_closest + st.rays_shadow
+        print(json.dumps({"scene": a.scene, "spp": a.spp, "rays": int(rays), "render_ms": st.render_ms,
+                          "mrays_per_s": rays / st.render_ms * 1e-3,
+                          "nodes_closest": int(st.nodes_closest), "nodes_shadow": int(st.nodes_shadow),
+                          "tri_tests_closest": int(st.tri_tests_closest), "tri_tests_shadow": int(st.tri_tests_shadow),
+                          "rays_closest": int(st.rays_closest), "rays_shadow": int(st.rays_shadow)}))
