@@ -9,10 +9,11 @@ resources/scenes/sponza.json at 1920x1080, depth 5.  sponza.obj and eight of its
 reference checkout, so the scene is the procedural atrium stand-in of pathtracer_amd/host/generators.cpp with
 the same triangle count (262,267), camera, light and 24 textured 1024^2 materials; `data` says so.
 
-One step = one pass of the hot path over one batch: --spp-per-step samples of every pixel (default 32, all in
-flight at once: 66.4 M paths), i.e. 1920 * 1080 * 32 = 66.4 M pixel samples per GPU and step.  Every rank renders its own sample indices of the
-same frame (weak scaling: per-GPU work per step is fixed); after the last step the per-GPU films are summed
-onto rank 0 with one RCCL reduce, inside the timed region.  --steps 32 on one GPU is the full 1024 spp frame.
+One step = one pass of the hot path over one batch: --spp-per-step samples of every pixel (default 128, all in
+flight at once: 265 M paths, 48 GB of path state), i.e. 1920 * 1080 * 128 = 265.4 M pixel samples per GPU and
+step.  Every rank renders its own sample indices of the same frame (weak scaling: per-GPU work per step is
+fixed); after the last step the per-GPU films are summed onto rank 0 with one RCCL reduce, inside the timed
+region.  The default --steps 8 on one GPU is the full 1024 spp frame.
 
 The JSON line carries `roofline` for the dominant kernel (closest-hit traversal or shadow-ray traversal,
 whichever took longer): algorithmic bytes from the kernel's own counters (32 B per node fetched, 48 B per
@@ -39,7 +40,7 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=8)
     p.add_argument("--warmup", type=int, default=2)
-    p.add_argument("--spp-per-step", type=int, default=32)
+    p.add_argument("--spp-per-step", type=int, default=128)
     p.add_argument("--width", type=int, default=1920)
     p.add_argument("--height", type=int, default=1080)
     p.add_argument("--triangles", type=int, default=262267)
@@ -148,7 +149,7 @@ def main():
         # newest committed rocprofv3 --pmc summary of this same command (profiles/collect_pmc.sh); null without one
         traffic, traffic_source = None, None
         summaries = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
-        profiled_workload = (args.spp_per_step, args.width, args.height, args.triangles, args.texture_size) == (32, 1920, 1080, 262267, 1024)
+        profiled_workload = (args.spp_per_step, args.width, args.height, args.triangles, args.texture_size) == (128, 1920, 1080, 262267, 1024)
         if summaries and profiled_workload:   # the committed counters are per launch of the default workload
             try:
                 entry = json.load(open(summaries[-1])).get(kernel, {})

@@ -623,14 +623,19 @@ int pt_render( PtScene* s, const PtRenderParams* p )
 
     const uint64_t pixels = static_cast< uint64_t >( s->width ) * s->height;
     const int totalSamples = p->sample_end - p->sample_begin;
-    // Samples of every pixel in flight at once: as many as fit 64 Mi paths, 24 GiB of path state and 32-bit shadow
-    // record indices.  Large passes matter: every traversal launch ends with waves draining their last, longest
-    // rays, a fixed cost per launch (measured at 1080p: 2 / 8 / 32 samples per pass = 1.59 / 2.44 / 2.76 Grays/s).
+    // Samples of every pixel in flight at once: as many as fit 256 Mi paths, 64 GiB of path state (and half of
+    // the memory that is free when the buffers have to grow) and 32-bit shadow record indices.  Large passes
+    // matter: every traversal launch ends with waves draining their last, longest rays, a fixed cost per launch
+    // (measured at 1080p: 2 / 8 / 32 / 128 samples per pass = 1.59 / 2.44 / 2.76 / 2.90 Grays/s).
     uint64_t perPass = p->samples_per_pass > 0 ? static_cast< uint64_t >( p->samples_per_pass ) : 0;
     if ( perPass == 0 )
     {
         const uint64_t slots = s->view.shadowSlots > 0 ? s->view.shadowSlots : 1;
-        uint64_t maxPaths = std::min< uint64_t >( 64ull << 20, ( 24ull << 30 ) / s->bytesPerPathFixed );
+        uint64_t budget = 64ull << 30;
+        size_t freeBytes = 0, totalBytes = 0;
+        if ( hipMemGetInfo( &freeBytes, &totalBytes ) == hipSuccess )
+            budget = std::min< uint64_t >( budget, std::max< uint64_t >( freeBytes / 2, s->paths.capacity * s->bytesPerPathFixed ) );
+        uint64_t maxPaths = std::min< uint64_t >( 256ull << 20, budget / s->bytesPerPathFixed );
         maxPaths = std::min< uint64_t >( maxPaths, 0xfffffffeull / slots - kUnitPaths );
         perPass = std::max< uint64_t >( 1, maxPaths / pixels );
     }

@@ -72,7 +72,7 @@ def test_atrium_1080p_matches_checker(atrium):
 
 def test_atrium_1080p_sample_splits_are_bit_identical(atrium):
     _, dev, _ = atrium
-    whole = check_split_is_bit_identical(dev, 24, 7, seed=5)   # 24 spp = three passes of 8
+    whole = check_split_is_bit_identical(dev, 24, 7, seed=5)   # one render against two calls (7 + 17 samples)
     assert whole.mean() > 0.01
 
 
