@@ -253,3 +253,65 @@ def test_film_checkpoint_and_resume_is_bit_identical(scenes):
         resumed, _, _ = dev.readback()
         assert (dev.download_film()[..., 3] == 8).all()
     assert_bits_equal(whole, resumed, "resumed render")
+
+
+def collapse_small_subtrees(scene, max_shapes):
+    """The same tree with every subtree of at most max_shapes primitives turned into one leaf (the node layout
+    of src/bvh.hpp:10-21 allows numShapes > 1 and BVH::Intersect loops over them, src/bvh.cpp:247-250, although
+    the reference's builders never emit such leaves)."""
+    old = scene.nodes
+    n = len(old)
+    end = np.zeros(n, np.int64)      # first node after the subtree
+    first = np.zeros(n, np.int64)    # first primitive of the subtree
+    count = np.zeros(n, np.int64)    # primitives in the subtree
+    for i in range(n - 1, -1, -1):
+        if old["num_shapes"][i] > 0:
+            end[i], first[i], count[i] = i + 1, old["offset"][i], old["num_shapes"][i]
+        else:
+            a, b = i + 1, int(old["offset"][i])
+            end[i], first[i], count[i] = end[b], first[a], count[a] + count[b]
+    keep, i = [], 0
+    while i < n:
+        keep.append(i)
+        i = end[i] if count[i] <= max_shapes else i + 1
+    new_index = {k: j for j, k in enumerate(keep)}
+    nodes = old[keep].copy()
+    for j, k in enumerate(keep):
+        if count[k] <= max_shapes:
+            nodes["offset"][j], nodes["num_shapes"][j] = first[k], count[k]
+        else:
+            nodes["offset"][j] = new_index[int(old["offset"][k])]
+    out = scene.copy()
+    out.nodes = nodes
+    return out
+
+
+@pytest.mark.parametrize("name,max_shapes", [("cornell", 2), ("cornell", 5), ("mixed", 3), ("mixed", 16)])
+def test_leaves_with_several_shapes(name, max_shapes, scenes):
+    scene = collapse_small_subtrees(scenes[name].with_image(40, 40), max_shapes)
+    assert scene.nodes["num_shapes"].max() > 1 and scene.nodes["num_shapes"].max() <= max_shapes
+    desc = scene.to_desc()
+    with api.DeviceScene(desc) as dev:
+        orc = checker.OracleScene(desc)
+        rng = np.random.default_rng(3)
+        n = 100_000
+        lo, hi = scene.nodes["aabb_min"][0], scene.nodes["aabb_max"][0]
+        o = rng.uniform(lo - 0.5, hi + 0.5, (n, 3)).astype(np.float32)
+        d = rng.normal(size=(n, 3)).astype(np.float32)
+        got, want = dev.trace_closest(o, d), orc.intersect(o, d)
+        assert np.array_equal(got["prim"], want["prim"])
+        for k in ("t", "u", "v"):
+            assert_bits_equal(got[k], want[k], k)
+        assert np.array_equal(got["nodes"], want["nodes"]) and np.array_equal(got["prim_tests"], want["prim_tests"])
+        # the closest hit does not depend on how the primitives are grouped into leaves
+        plain = checker.OracleScene(scenes[name].to_desc()).intersect(o, d)
+        assert np.array_equal(plain["prim"], want["prim"])
+        tmax = rng.uniform(0, 3, n).astype(np.float32)
+        got, want = dev.trace_any(o, d, tmax), orc.occluded(o, d, tmax)
+        assert np.array_equal(got["occluded"], want["occluded"]) and np.array_equal(got["nodes"], want["nodes"])
+        dev.render(4, seed=6)
+        lin, _, stats = dev.readback()
+        ref, ostats = orc.li_image(4, seed=6)
+        radiance_close(lin, ref / np.float32(4), f"{name}, leaves of up to {max_shapes}")
+        assert stats.nodes_closest == ostats["nodes_closest"] and stats.tri_tests_closest == ostats["tri_tests_closest"]
+        assert stats.sphere_tests_closest == ostats["sphere_tests_closest"]
