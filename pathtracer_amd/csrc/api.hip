@@ -92,6 +92,7 @@ struct PtScene
     int gridBlocks = 2048;
     int extendBlocks = 1024, connectBlocks = 1024; // resident grids of the traversal kernels
     uint32_t topNodes = 0;                          // nodes at the front of the device array in breadth-first order
+    bool directSum = false;                         // one light with one sample: ConnectKernel adds the direct light, no ResolveKernel
 
     // scene
     DeviceBuffer nodes, prims, triShade, spheres, materials, textures, texels, lights, skybox;
@@ -415,6 +416,7 @@ int Upload( PtScene* s, const PtSceneDesc* d, const std::vector< uint32_t >& esc
     v.numSpheres    = static_cast< uint32_t >( d->num_spheres );
     v.numLights     = static_cast< uint32_t >( d->num_lights );
     v.shadowSlots   = slots;
+    s->directSum    = d->num_lights == 1 && d->lights[0].n_samples == 1 && !std::getenv( "PT_NO_DIRECT_SUM" );
     v.drawsPerBounce = static_cast< int32_t >( 2 * areaSamples + 2 );
     v.skyboxWidth   = d->skybox_width;
     v.skyboxHeight  = d->skybox_height;
@@ -482,6 +484,7 @@ int EnsurePathBuffers( PtScene* s, uint64_t capacity )
     p.cursors     = s->cursors.As< uint32_t >();
     p.capacity    = capacity;
     p.shadowSlots = static_cast< uint32_t >( slots );
+    p.directSum   = s->directSum ? 1u : 0u;
     return PT_OK;
 }
 
@@ -697,9 +700,12 @@ int pt_render( PtScene* s, const PtRenderParams* p )
                 span = timer.Begin( PT_K_CONNECT );
                 LaunchConnect( cfg, s->view, pb, bounce, stats );
                 timer.End( span );
-                span = timer.Begin( PT_K_RESOLVE );
-                LaunchResolve( cfg, s->view, pb, bounce );
-                timer.End( span );
+                if ( !pb.directSum )
+                {
+                    span = timer.Begin( PT_K_RESOLVE );
+                    LaunchResolve( cfg, s->view, pb, bounce );
+                    timer.End( span );
+                }
             }
         }
         span = timer.Begin( PT_K_FILM );

@@ -765,7 +765,11 @@ __global__ __launch_bounds__( kTraverseBlock ) PT_TRAVERSE_OCCUPANCY void Extend
 
 // Visibility of the queued shadow rays: BVH::Occluded (src/bvh.cpp:270-310) under Scene::Occluded
 // (src/scene.cpp:381-384), same scheduling as ExtendKernel.  One work item per shadow record; an occluded
-// record gets the distance -2 written back, so that ResolveKernel leaves it out of the sum.
+// record gets the distance -2 written back, so that ResolveKernel leaves it out of the sum.  kDirectSum: the
+// scene has one light with one sample, so a path has at most one record per bounce and its record holds
+// throughput * LDirect and the path id (ShadeKernel): an unoccluded record is added to the path's radiance
+// here (path_tracer.cpp:133-134) and ResolveKernel does not run.
+template < bool kDirectSum >
 __global__ __launch_bounds__( kTraverseBlock ) PT_TRAVERSE_OCCUPANCY void ConnectKernel( SceneView sv, PathBuffers pb, int bounce, uint64_t* stats )
 {
     UnitStream stream{ pb.cursors + 2 * bounce + 1, UnitCount( pb, bounce, kCountShadowRays, 0 ), pb.units, kUnitPaths * pb.shadowSlots, 0u };
@@ -797,7 +801,17 @@ __global__ __launch_bounds__( kTraverseBlock ) PT_TRAVERSE_OCCUPANCY void Connec
 
         if ( mRay && ( __popcll( mRay ) >= kConnectRefillLanes || ( mTrav | mLeaf ) == 0 ) )
         {
-            if ( idle && rec != kNoRay && occluded ) reinterpret_cast< float* >( pb.shDir )[4ull * rec + 3] = -2.0f;
+            if constexpr ( kDirectSum )
+            {
+                if ( idle && rec != kNoRay && !occluded )
+                {
+                    const float4 e = pb.shEst[rec];
+                    const uint32_t p = __float_as_uint( e.w );
+                    pb.rad[p] = F4( F3( pb.rad[p] ) + F3( e ), 0.0f );
+                }
+            }
+            else if ( idle && rec != kNoRay && occluded )
+                reinterpret_cast< float* >( pb.shDir )[4ull * rec + 3] = -2.0f;
             if ( idle ) rec = kNoRay;
             while ( !stream.ended )
             {
@@ -1098,8 +1112,16 @@ __global__ __launch_bounds__( kBlock ) void ShadeKernel( SceneView sv, RngParams
                     pb.shDir[rec] = F4( wi, skip ? -1.0f : tMax );
                     if ( !skip )
                     {
-                        pb.shEst[rec] = F4( est, 0.0f );
-                        anyShadow     = true;
+                        if ( pb.directSum )
+                        {
+                            // what ResolveKernel computes for one light with one sample, in its order
+                            const f3 zero = F3( 0.0f, 0.0f, 0.0f ), Ld = zero + est;
+                            const f3 Ldirect = zero + Ld / 1.0f;
+                            pb.shEst[rec] = F4( T * Ldirect, __uint_as_float( p ) );
+                        }
+                        else
+                            pb.shEst[rec] = F4( est, 0.0f );
+                        anyShadow = true;
                     }
                 }
                 SegmentAppend( !skip, rec, outShadowRays, nShadowRays );
@@ -1140,7 +1162,7 @@ __global__ __launch_bounds__( kBlock ) void ShadeKernel( SceneView sv, RngParams
             }
             nNext += static_cast< uint32_t >( __popcll( mAlive ) );
         }
-        SegmentAppend( anyShadow, q, outShadowPaths, nShadowPaths );
+        if ( !pb.directSum ) SegmentAppend( anyShadow, q, outShadowPaths, nShadowPaths ); // ResolveKernel's work list
         if constexpr ( !kSphereHits ) SegmentAppend( deferred, q, pb.sphereQueue + segment, nSpheres );
     }
     if ( LaneIndex() == 0 )
@@ -1305,7 +1327,7 @@ void TraversalOccupancy( int* extendBlocksPerCu, int* connectBlocksPerCu )
 {
     int e = 0, c = 0;
     if ( hipOccupancyMaxActiveBlocksPerMultiprocessor( &e, ExtendKernel, kTraverseBlock, 0 ) != hipSuccess || e < 1 ) e = 4;
-    if ( hipOccupancyMaxActiveBlocksPerMultiprocessor( &c, ConnectKernel, kTraverseBlock, 0 ) != hipSuccess || c < 1 ) c = 4;
+    if ( hipOccupancyMaxActiveBlocksPerMultiprocessor( &c, ConnectKernel< false >, kTraverseBlock, 0 ) != hipSuccess || c < 1 ) c = 4;
     *extendBlocksPerCu  = e;
     *connectBlocksPerCu = c;
 }
@@ -1334,7 +1356,10 @@ void LaunchShade( const LaunchCfg& cfg, const SceneView& sv, const RngParams& rn
 
 void LaunchConnect( const LaunchCfg& cfg, const SceneView& sv, const PathBuffers& pb, int bounce, uint64_t* stats )
 {
-    hipLaunchKernelGGL( ConnectKernel, dim3( cfg.connectBlocks ), dim3( kTraverseBlock ), 0, cfg.stream, sv, pb, bounce, stats );
+    if ( pb.directSum )
+        hipLaunchKernelGGL( ConnectKernel< true >, dim3( cfg.connectBlocks ), dim3( kTraverseBlock ), 0, cfg.stream, sv, pb, bounce, stats );
+    else
+        hipLaunchKernelGGL( ConnectKernel< false >, dim3( cfg.connectBlocks ), dim3( kTraverseBlock ), 0, cfg.stream, sv, pb, bounce, stats );
 }
 
 void LaunchResolve( const LaunchCfg& cfg, const SceneView& sv, const PathBuffers& pb, int bounce )

@@ -108,7 +108,7 @@ struct PathBuffers
     float4* rad;       // [path] accumulated radiance of the path
     float4* shadowO;   // [entry] origin of the path's shadow rays of this bounce
     float4* shDir;     // [slot * entries + entry]: wi.xyz, tMax (-1 = no ray, -2 = occluded); entries = units * kUnitPaths
-    float4* shEst;     // [slot * entries + entry]: unoccluded contribution
+    float4* shEst;     // [slot * entries + entry]: unoccluded contribution; with directSum: throughput * contribution, path id
     uint32_t* queue[2];     // [entry] path id, double buffered per bounce
     uint32_t* shadowPaths;  // entries (of this bounce's queue) whose path cast at least one shadow ray
     uint32_t* shadowRays;   // shadow record indices (slot * entries + entry) to test for occlusion, kUnitPaths * slots per unit
@@ -118,6 +118,7 @@ struct PathBuffers
     uint64_t capacity;      // paths in flight; units * kUnitPaths * shadow slots < 2^32
     uint32_t units;         // units of kUnitPaths consecutive path ids in this pass
     uint32_t shadowSlots;   // shadow records per path, at least 1
+    uint32_t directSum;     // 1: one light with one sample - ConnectKernel adds the direct light itself, no ResolveKernel
 };
 
 // Paths per unit of work; every queue has one segment of this many entries (times shadowSlots for shadowRays) per unit

@@ -315,3 +315,27 @@ def test_leaves_with_several_shapes(name, max_shapes, scenes):
         radiance_close(lin, ref / np.float32(4), f"{name}, leaves of up to {max_shapes}")
         assert stats.nodes_closest == ostats["nodes_closest"] and stats.tri_tests_closest == ostats["tri_tests_closest"]
         assert stats.sphere_tests_closest == ostats["sphere_tests_closest"]
+
+
+@pytest.mark.parametrize("name,keep", [("mixed", 0), ("mixed", 1), ("cornell", 0)])
+def test_single_light_direct_sum_equals_resolve_pass(name, keep, scenes, monkeypatch):
+    """With one light and one sample per hit the shadow-ray kernel adds the direct light itself; with
+    PT_NO_DIRECT_SUM set at upload the separate summation pass runs instead.  Same film, bit for bit, and both
+    match the checker."""
+    scene = scenes[name].with_image(40, 40)
+    scene.lights = scene.lights[keep:keep + 1].copy()
+    scene.lights["n_samples"] = 1
+    desc = scene.to_desc()
+    want, _ = checker.OracleScene(desc).li_image(8, seed=4)
+    films = []
+    for separate_pass in (False, True):
+        if separate_pass:
+            monkeypatch.setenv("PT_NO_DIRECT_SUM", "1")
+        with api.DeviceScene(desc) as dev:
+            dev.render(8, seed=4)
+            lin, _, stats = dev.readback()
+            assert stats.rays_shadow > 0
+            assert (stats.launches[abi.PT_K_RESOLVE] > 0) == separate_pass
+            films.append(lin)
+    assert_bits_equal(films[0], films[1], "direct sum in the shadow-ray kernel vs separate pass")
+    radiance_close(films[0], want / np.float32(8), f"{name}, light {keep} only")
