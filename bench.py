@@ -147,7 +147,7 @@ def main():
         achieved = kbytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
         # bytes that left the L2 per launch of that kernel (reads corrected for gfx950, writes as counted), from the
         # newest committed rocprofv3 --pmc summary of this same command (profiles/collect_pmc.sh); null without one
-        traffic, traffic_source = None, None
+        traffic, traffic_source, profiled = None, None, {}
         summaries = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
         profiled_workload = (args.spp_per_step, args.width, args.height, args.triangles, args.texture_size) == (128, 1920, 1080, 262267, 1024)
         if summaries and profiled_workload:   # the committed counters are per launch of the default workload
@@ -156,6 +156,9 @@ def main():
                 if "fabric_read_bytes" in entry:
                     traffic = round(entry["fabric_read_bytes"] + entry.get("fabric_write_bytes", 0.0))
                     traffic_source = os.path.relpath(summaries[-1], ROOT)
+                # the other figures of that profile the path is judged on: hit rates, vector issue utilisation, waiting
+                profiled = {k: round(entry[k], 4) for k in ("l1_hit_rate", "l2_hit_rate", "valu_utilization",
+                                                             "wave_time_waiting_on_memory") if k in entry}
             except (OSError, ValueError):
                 pass
         roofline = {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -164,7 +167,7 @@ def main():
                     "launches": klaunch, "bytes_per_ray": round(kbytes / max(1, krays), 1),
                     "grays_per_s_in_kernel": round(krays / (kms * 1e-3) / 1e9, 3) if kms > 0 else 0.0,
                     "nodes_per_ray": round(knodes / max(1, krays), 2),
-                    "lanes_per_node_step": round(knodes / max(1, ksteps), 2),
+                    "lanes_per_node_step": round(knodes / max(1, ksteps), 2), "profiled": profiled,
                     "note": "algorithmic bytes = the reference's per-ray byte model times the kernel's own counters; "
                             "`traffic` is what left the L2 (the 29 MB of nodes and primitive records are served from "
                             "L1 / L2 / Infinity Cache after the first touch), so the fraction can exceed 1"}

@@ -4,7 +4,9 @@ a table.  usage: python summarize_pmc.py <dir>
 
 Derived per-dispatch figures: fabric_read_bytes = FETCH_SIZE (KiB) * 1024 * 2 -- on gfx950 FETCH_SIZE tallies
 the memory-side read requests at half their size; fabric_write_bytes = WRITE_SIZE (KiB) * 1024.  Both count
-requests that leave the L2, including those the Infinity Cache serves."""
+requests that leave the L2, including those the Infinity Cache serves.  valu_utilization = SQ_ACTIVE_INST_VALU
+(wave instructions issued, summed over the chip) * 4 cycles per wave64 instruction / (GRBM_GUI_ACTIVE / 8 XCDs,
+the kernel's duration in cycles) / 1024 SIMDs: the share of the SIMDs' vector issue slots the kernel uses."""
 import csv, glob, json, os, sys
 from collections import defaultdict
 
@@ -37,6 +39,8 @@ for k in sorted(tot):
         d["l1_hit_rate"] = 1 - per.get("TCP_TCC_READ_REQ_sum", 0) / per["TCP_TOTAL_CACHE_ACCESSES_sum"]
     if "TCC_REQ_sum" in per and per["TCC_REQ_sum"] > 0:
         d["l2_hit_rate"] = 1 - per.get("TCC_MISS_sum", 0) / per["TCC_REQ_sum"]
+    if "SQ_ACTIVE_INST_VALU" in per and per.get("GRBM_GUI_ACTIVE", 0) > 0:
+        d["valu_utilization"] = per["SQ_ACTIVE_INST_VALU"] * 4 / (per["GRBM_GUI_ACTIVE"] / 8) / 1024
     if "SQ_WAVE_CYCLES" in per and per["SQ_WAVE_CYCLES"] > 0:
         d["wave_time_waiting_on_memory"] = per.get("SQ_WAIT_ANY", 0) / per["SQ_WAVE_CYCLES"]
         d["wave_time_issue_stalled"] = per.get("SQ_WAIT_INST_ANY", 0) / per["SQ_WAVE_CYCLES"]
