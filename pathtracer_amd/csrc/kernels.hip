@@ -632,8 +632,18 @@ __device__ __forceinline__ void FlushWaveCounter( uint64_t* stats, int slot, uin
 #define PT_TRAVERSE_WAVES 6
 #endif
 #define PT_TRAVERSE_OCCUPANCY __attribute__( ( amdgpu_waves_per_eu( PT_TRAVERSE_WAVES, PT_TRAVERSE_WAVES ) ) )
+// The any-hit kernel keeps less per lane (no u, v, primitive; 63 VGPRs) and runs 8 waves per SIMD: 1,024 threads,
+// two workgroups per CU.  Measured against 768 x 2 (6 waves): -4.7 % per launch; 896 x 2 (7 waves, 72 VGPRs): +32 %.
+#ifndef PT_CONNECT_BLOCK
+#define PT_CONNECT_BLOCK 1024
+#endif
+#ifndef PT_CONNECT_WAVES
+#define PT_CONNECT_WAVES 8
+#endif
+#define PT_CONNECT_OCCUPANCY __attribute__( ( amdgpu_waves_per_eu( PT_CONNECT_WAVES, PT_CONNECT_WAVES ) ) )
 constexpr uint32_t kLdsTopNodes = PT_LDS_TOP_NODES;
 constexpr int kTraverseBlock    = PT_TRAVERSE_BLOCK;
+constexpr int kConnectBlock     = PT_CONNECT_BLOCK;
 constexpr int kExtendRefillLanes  = PT_EXTEND_REFILL_LANES;
 constexpr int kConnectRefillLanes = PT_CONNECT_REFILL_LANES;
 constexpr int kLeafLanes     = PT_LEAF_LANES;
@@ -770,7 +780,7 @@ __global__ __launch_bounds__( kTraverseBlock ) PT_TRAVERSE_OCCUPANCY void Extend
 // throughput * LDirect and the path id (ShadeKernel): an unoccluded record is added to the path's radiance
 // here (path_tracer.cpp:133-134) and ResolveKernel does not run.
 template < bool kDirectSum >
-__global__ __launch_bounds__( kTraverseBlock ) PT_TRAVERSE_OCCUPANCY void ConnectKernel( SceneView sv, PathBuffers pb, int bounce, uint64_t* stats )
+__global__ __launch_bounds__( kConnectBlock ) PT_CONNECT_OCCUPANCY void ConnectKernel( SceneView sv, PathBuffers pb, int bounce, uint64_t* stats )
 {
     UnitStream stream{ pb.cursors + 2 * bounce + 1, UnitCount( pb, bounce, kCountShadowRays, 0 ), pb.units, kUnitPaths * pb.shadowSlots, 0u };
     const uint32_t end      = sv.numNodes;
@@ -780,7 +790,7 @@ __global__ __launch_bounds__( kTraverseBlock ) PT_TRAVERSE_OCCUPANCY void Connec
     const uint32_t topCount = kLdsTopNodes < sv.numTopNodes ? kLdsTopNodes : sv.numTopNodes;
     if ( kLdsTopNodes > 0 )
     {
-        for ( uint32_t i = threadIdx.x; i < 2 * topCount; i += kTraverseBlock ) topLds[i] = Load16( sb.nodes, 16u * i );
+        for ( uint32_t i = threadIdx.x; i < 2 * topCount; i += kConnectBlock ) topLds[i] = Load16( sb.nodes, 16u * i );
         __syncthreads();
     }
     uint32_t rec = kNoRay, node = end, leaf = kInnerNode;
@@ -1327,7 +1337,7 @@ void TraversalOccupancy( int* extendBlocksPerCu, int* connectBlocksPerCu )
 {
     int e = 0, c = 0;
     if ( hipOccupancyMaxActiveBlocksPerMultiprocessor( &e, ExtendKernel, kTraverseBlock, 0 ) != hipSuccess || e < 1 ) e = 4;
-    if ( hipOccupancyMaxActiveBlocksPerMultiprocessor( &c, ConnectKernel< false >, kTraverseBlock, 0 ) != hipSuccess || c < 1 ) c = 4;
+    if ( hipOccupancyMaxActiveBlocksPerMultiprocessor( &c, ConnectKernel< false >, kConnectBlock, 0 ) != hipSuccess || c < 1 ) c = 4;
     *extendBlocksPerCu  = e;
     *connectBlocksPerCu = c;
 }
@@ -1357,9 +1367,9 @@ void LaunchShade( const LaunchCfg& cfg, const SceneView& sv, const RngParams& rn
 void LaunchConnect( const LaunchCfg& cfg, const SceneView& sv, const PathBuffers& pb, int bounce, uint64_t* stats )
 {
     if ( pb.directSum )
-        hipLaunchKernelGGL( ConnectKernel< true >, dim3( cfg.connectBlocks ), dim3( kTraverseBlock ), 0, cfg.stream, sv, pb, bounce, stats );
+        hipLaunchKernelGGL( ConnectKernel< true >, dim3( cfg.connectBlocks ), dim3( kConnectBlock ), 0, cfg.stream, sv, pb, bounce, stats );
     else
-        hipLaunchKernelGGL( ConnectKernel< false >, dim3( cfg.connectBlocks ), dim3( kTraverseBlock ), 0, cfg.stream, sv, pb, bounce, stats );
+        hipLaunchKernelGGL( ConnectKernel< false >, dim3( cfg.connectBlocks ), dim3( kConnectBlock ), 0, cfg.stream, sv, pb, bounce, stats );
 }
 
 void LaunchResolve( const LaunchCfg& cfg, const SceneView& sv, const PathBuffers& pb, int bounce )
