@@ -561,7 +561,7 @@ int pt_upload_scene( const PtSceneDesc* desc, PtScene** out )
     if ( hipGetDeviceProperties( &prop, desc->device ) == hipSuccess && prop.multiProcessorCount > 0 ) s->gridBlocks = prop.multiProcessorCount * 8;
     {
         int extendPerCu = 0, connectPerCu = 0;
-        TraversalOccupancy( &extendPerCu, &connectPerCu );
+        TraversalOccupancy( desc->num_spheres > 0, &extendPerCu, &connectPerCu );
         const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         s->extendBlocks  = extendPerCu * cus;
         s->connectBlocks = connectPerCu * cus;

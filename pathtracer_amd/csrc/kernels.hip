@@ -192,12 +192,13 @@ struct HitRecord
 // One primitive test of a closest-hit leaf: Triangle::Intersect / Sphere::Intersect (src/shapes.cpp:117-123,
 // 52-61).  The record (48 bytes of a 64-byte slot) is fetched whole before its tag is looked at (one memory round trip); the
 // triangle arithmetic runs on whatever was fetched and is discarded for a sphere record.
+template < bool kSpheres = true >
 __device__ __forceinline__ void ClosestPrimTest( const SceneView& sv, const SceneBuffers& sb, uint32_t prim, f3 o, f3 d, HitRecord& h, bool* wasSphere )
 {
     const float4 q0 = Load16( sb.prims, 64u * prim ), q1 = Load16( sb.prims, 64u * prim + 16u ), q2 = Load16( sb.prims, 64u * prim + 32u );
     float t = 0.0f, u = 0.0f, v = 0.0f;
     bool hit   = RayTriangle( o, d, F3( q0 ), F3( q1 ), F3( q2 ), h.t, &t, &u, &v );
-    *wasSphere = __float_as_uint( q0.w ) != kTagTriangle;
+    *wasSphere = kSpheres && __float_as_uint( q0.w ) != kTagTriangle; // a scene without spheres has triangle records only
     if ( *wasSphere )
     {
         // closest-hit sphere test runs in the sphere's local space against the unit sphere
@@ -634,6 +635,12 @@ __device__ __forceinline__ void FlushWaveCounter( uint64_t* stats, int slot, uin
 #define PT_TRAVERSE_OCCUPANCY __attribute__( ( amdgpu_waves_per_eu( PT_TRAVERSE_WAVES, PT_TRAVERSE_WAVES ) ) )
 // The any-hit kernel keeps less per lane (no u, v, primitive; 63 VGPRs) and runs 8 waves per SIMD: 1,024 threads,
 // two workgroups per CU.  Measured against 768 x 2 (6 waves): -4.7 % per launch; 896 x 2 (7 waves, 72 VGPRs): +32 %.
+#ifndef PT_TRIANGLE_BLOCK
+#define PT_TRIANGLE_BLOCK 1024
+#endif
+#ifndef PT_TRIANGLE_WAVES
+#define PT_TRIANGLE_WAVES 8
+#endif
 #ifndef PT_CONNECT_BLOCK
 #define PT_CONNECT_BLOCK 1024
 #endif
@@ -644,6 +651,7 @@ __device__ __forceinline__ void FlushWaveCounter( uint64_t* stats, int slot, uin
 constexpr uint32_t kLdsTopNodes = PT_LDS_TOP_NODES;
 constexpr int kTraverseBlock    = PT_TRAVERSE_BLOCK;
 constexpr int kConnectBlock     = PT_CONNECT_BLOCK;
+constexpr int kTriangleBlock    = PT_TRIANGLE_BLOCK;
 constexpr int kExtendRefillLanes  = PT_EXTEND_REFILL_LANES;
 constexpr int kConnectRefillLanes = PT_CONNECT_REFILL_LANES;
 constexpr int kLeafLanes     = PT_LEAF_LANES;
@@ -651,7 +659,8 @@ constexpr int kTraverseBurst = PT_TRAVERSE_BURST;
 
 // Closest hits of the rays entering `bounce`: BVH::Intersect (src/bvh.cpp:230-268) under Scene::Intersect
 // (src/scene.cpp:370-373).
-__global__ __launch_bounds__( kTraverseBlock ) PT_TRAVERSE_OCCUPANCY void ExtendKernel( SceneView sv, PathBuffers pb, int bounce, uint32_t numPaths, uint64_t* stats )
+template < bool kSpheres >
+__global__ __launch_bounds__( kSpheres ? kTraverseBlock : kTriangleBlock ) __attribute__( ( amdgpu_waves_per_eu( kSpheres ? PT_TRAVERSE_WAVES : PT_TRIANGLE_WAVES, kSpheres ? PT_TRAVERSE_WAVES : PT_TRIANGLE_WAVES ) ) ) void ExtendKernel( SceneView sv, PathBuffers pb, int bounce, uint32_t numPaths, uint64_t* stats )
 {
     UnitStream stream{ pb.cursors + 2 * bounce, bounce == 0 ? nullptr : UnitCount( pb, bounce - 1, kCountNextPaths, 0 ), pb.units, kUnitPaths, numPaths };
     const float4* rayO = pb.rayO[bounce & 1];
@@ -662,7 +671,7 @@ __global__ __launch_bounds__( kTraverseBlock ) PT_TRAVERSE_OCCUPANCY void Extend
     const uint32_t topCount = kLdsTopNodes < sv.numTopNodes ? kLdsTopNodes : sv.numTopNodes;
     if ( kLdsTopNodes > 0 )
     {
-        for ( uint32_t i = threadIdx.x; i < 2 * topCount; i += kTraverseBlock ) topLds[i] = Load16( sb.nodes, 16u * i );
+        for ( uint32_t i = threadIdx.x; i < 2 * topCount; i += ( kSpheres ? kTraverseBlock : kTriangleBlock ) ) topLds[i] = Load16( sb.nodes, 16u * i );
         __syncthreads();
     }
     // node: the node to visit next (or, while a leaf is pending, the node to go to after it); leaf: pending leaf word
@@ -722,7 +731,7 @@ __global__ __launch_bounds__( kTraverseBlock ) PT_TRAVERSE_OCCUPANCY void Extend
                 bool isTri = false, isSphere = false;
                 if ( k < shapes )
                 {
-                    ClosestPrimTest( sv, sb, first + k, o, d, h, &isSphere );
+                    ClosestPrimTest< kSpheres >( sv, sb, first + k, o, d, h, &isSphere );
                     isTri = !isSphere;
                 }
                 waveTris += LanesSet( isTri );
@@ -1333,10 +1342,12 @@ static int GridFor( const LaunchCfg& cfg, uint64_t work )
 // One unit per wave, four waves per block
 static dim3 UnitGrid( const PathBuffers& pb ) { return dim3( ( pb.units + kBlock / 64 - 1 ) / ( kBlock / 64 ) ); }
 
-void TraversalOccupancy( int* extendBlocksPerCu, int* connectBlocksPerCu )
+void TraversalOccupancy( bool spheres, int* extendBlocksPerCu, int* connectBlocksPerCu )
 {
     int e = 0, c = 0;
-    if ( hipOccupancyMaxActiveBlocksPerMultiprocessor( &e, ExtendKernel, kTraverseBlock, 0 ) != hipSuccess || e < 1 ) e = 4;
+    const hipError_t rc = spheres ? hipOccupancyMaxActiveBlocksPerMultiprocessor( &e, ExtendKernel< true >, kTraverseBlock, 0 )
+                                  : hipOccupancyMaxActiveBlocksPerMultiprocessor( &e, ExtendKernel< false >, kTriangleBlock, 0 );
+    if ( rc != hipSuccess || e < 1 ) e = 2;
     if ( hipOccupancyMaxActiveBlocksPerMultiprocessor( &c, ConnectKernel< false >, kConnectBlock, 0 ) != hipSuccess || c < 1 ) c = 4;
     *extendBlocksPerCu  = e;
     *connectBlocksPerCu = c;
@@ -1350,7 +1361,10 @@ void LaunchRaygen( const LaunchCfg& cfg, const CameraFrame& cam, const RngParams
 
 void LaunchExtend( const LaunchCfg& cfg, const SceneView& sv, const PathBuffers& pb, int bounce, uint32_t numPaths, uint64_t* stats )
 {
-    hipLaunchKernelGGL( ExtendKernel, dim3( cfg.extendBlocks ), dim3( kTraverseBlock ), 0, cfg.stream, sv, pb, bounce, numPaths, stats );
+    if ( sv.numSpheres )
+        hipLaunchKernelGGL( ExtendKernel< true >, dim3( cfg.extendBlocks ), dim3( kTraverseBlock ), 0, cfg.stream, sv, pb, bounce, numPaths, stats );
+    else
+        hipLaunchKernelGGL( ExtendKernel< false >, dim3( cfg.extendBlocks ), dim3( kTriangleBlock ), 0, cfg.stream, sv, pb, bounce, numPaths, stats );
 }
 
 void LaunchShade( const LaunchCfg& cfg, const SceneView& sv, const RngParams& rng, const PathBuffers& pb, int bounce, int maxDepth,

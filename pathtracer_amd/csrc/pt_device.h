@@ -149,7 +149,7 @@ struct LaunchCfg
 void LaunchRaygen( const LaunchCfg& cfg, const CameraFrame& cam, const RngParams& rng, const PathBuffers& pb,
                    uint32_t width, uint32_t height, uint32_t sampleBegin, uint32_t numPaths );
 // resident blocks per compute unit of the two traversal kernels (occupancy query)
-void TraversalOccupancy( int* extendBlocksPerCu, int* connectBlocksPerCu );
+void TraversalOccupancy( bool spheres, int* extendBlocksPerCu, int* connectBlocksPerCu );
 void LaunchExtend( const LaunchCfg& cfg, const SceneView& sv, const PathBuffers& pb, int bounce, uint32_t numPaths, uint64_t* stats );
 void LaunchShade( const LaunchCfg& cfg, const SceneView& sv, const RngParams& rng, const PathBuffers& pb, int bounce,
                   int maxDepth, uint32_t width, uint32_t height, uint32_t sampleBegin, uint32_t numPaths, uint64_t* stats );
