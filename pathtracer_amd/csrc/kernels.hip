@@ -605,7 +605,7 @@ __device__ __forceinline__ void FlushWaveCounter( uint64_t* stats, int slot, uin
 // A phase also runs as soon as nothing else can make progress, so every lane terminates.  Per ray the sequence
 // of node visits and primitive tests is unchanged: a waiting lane does nothing, it never runs ahead.
 #ifndef PT_EXTEND_REFILL_LANES
-#define PT_EXTEND_REFILL_LANES 16
+#define PT_EXTEND_REFILL_LANES 24
 #endif
 #ifndef PT_CONNECT_REFILL_LANES
 #define PT_CONNECT_REFILL_LANES 32
@@ -618,8 +618,8 @@ __device__ __forceinline__ void FlushWaveCounter( uint64_t* stats, int slot, uin
 #endif
 // The traversal kernels keep the first kLdsTopNodes nodes of the (breadth-first ordered) node array in LDS, one copy
 // per workgroup, and read them with ds_read instead of going through the texture addresser and the L1 - the
-// busiest unit of these kernels.  Large workgroups share one copy between more waves: 768 threads (12 waves), two
-// workgroups per CU (6 waves per SIMD, 80 VGPRs), 2,400 nodes = 75 KB each.  Measured, extend per launch of
+// busiest unit of these kernels.  Large workgroups share one copy between more waves: two workgroups per CU,
+// 2,400 nodes = 75 KB each; 768 threads (6 waves per SIMD) at 80 VGPRs, 1,024 threads (8 waves per SIMD) at 64.  Measured, extend per launch of
 // 66.4 M paths: no LDS copy, 256 threads x 7 per CU, 17.6 ms; 384 / 704 nodes in that shape 15.9 / 14.9 ms;
 // 512 threads x 3 with 1,600 nodes 14.1 ms; 768 x 2 with 2,400 nodes 14.0 ms.  (Without the copy 7 waves per SIMD
 // beat 6 by 7 % and 8, which spills in the node loop, lost 6 %.)
@@ -635,6 +635,7 @@ __device__ __forceinline__ void FlushWaveCounter( uint64_t* stats, int slot, uin
 #define PT_TRAVERSE_OCCUPANCY __attribute__( ( amdgpu_waves_per_eu( PT_TRAVERSE_WAVES, PT_TRAVERSE_WAVES ) ) )
 // The any-hit kernel keeps less per lane (no u, v, primitive; 63 VGPRs) and runs 8 waves per SIMD: 1,024 threads,
 // two workgroups per CU.  Measured against 768 x 2 (6 waves): -4.7 % per launch; 896 x 2 (7 waves, 72 VGPRs): +32 %.
+// ExtendKernel< false > (no sphere path, 61 VGPRs) runs 8 waves per SIMD: -2.5 % per launch against 6
 #ifndef PT_TRIANGLE_BLOCK
 #define PT_TRIANGLE_BLOCK 1024
 #endif
