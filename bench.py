@@ -152,7 +152,9 @@ def main():
         profiled_workload = (args.spp_per_step, args.width, args.height, args.triangles, args.texture_size) == (128, 1920, 1080, 262267, 1024)
         if summaries and profiled_workload:   # the committed counters are per launch of the default workload
             try:
-                entry = json.load(open(summaries[-1])).get(kernel, {})
+                summary = json.load(open(summaries[-1]))
+                # the kernels are template instances there ("ExtendKernel<false>"); the workload runs one of each
+                entry = next((v for k, v in sorted(summary.items()) if k.split("<")[0] == kernel), {})
                 if "fabric_read_bytes" in entry:
                     traffic = round(entry["fabric_read_bytes"] + entry.get("fabric_write_bytes", 0.0))
                     traffic_source = os.path.relpath(summaries[-1], ROOT)
