@@ -195,7 +195,11 @@ struct HitRecord
 template < bool kSpheres = true >
 __device__ __forceinline__ void ClosestPrimTest( const SceneView& sv, const SceneBuffers& sb, uint32_t prim, f3 o, f3 d, HitRecord& h, bool* wasSphere )
 {
-    const float4 q0 = Load16( sb.prims, 64u * prim ), q1 = Load16( sb.prims, 64u * prim + 16u ), q2 = Load16( sb.prims, 64u * prim + 32u );
+    float4 q0 = Load16( sb.prims, 64u * prim );
+    const float4 q1 = Load16( sb.prims, 64u * prim + 16u ), q2 = Load16( sb.prims, 64u * prim + 32u );
+    // Without the tag test nothing needs v0 before the determinant is known, and the compiler moves its load
+    // behind that branch: a second memory round trip per leaf.  The empty statement pins the load up here.
+    if constexpr ( !kSpheres ) asm volatile( "" : "+v"( q0.x ), "+v"( q0.y ), "+v"( q0.z ) );
     float t = 0.0f, u = 0.0f, v = 0.0f;
     bool hit   = RayTriangle( o, d, F3( q0 ), F3( q1 ), F3( q2 ), h.t, &t, &u, &v );
     *wasSphere = kSpheres && __float_as_uint( q0.w ) != kTagTriangle; // a scene without spheres has triangle records only
