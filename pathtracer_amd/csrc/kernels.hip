@@ -851,8 +851,12 @@ __global__ __launch_bounds__( kConnectBlock ) PT_CONNECT_OCCUPANCY void ConnectK
                 if ( idle && rec == kNoRay && rank < left )
                 {
                     rec = pb.shadowRays[stream.base + stream.taken + rank];
-                    const float4 dir = pb.shDir[rec];
-                    o    = F3( pb.shadowO[pb.shadowSlots == 1 ? rec : rec % entries] ); // record index = slot * entries + entry
+                    uint32_t entry = pb.shadowSlots == 1 ? rec : rec % entries; // record index = slot * entries + entry
+                    asm volatile( "" : "+v"( entry ) );                              // the index first, then both loads in one go
+                    float4 dir = pb.shDir[rec];
+                    float4 org = pb.shadowO[entry];
+                    asm volatile( "" : "+v"( dir.x ), "+v"( org.x ) ); // both loads in flight before either is waited for
+                    o    = F3( org );
                     d    = F3( dir );
                     tMax = dir.w;
                     inv  = F3( 1.0f / d.x, 1.0f / d.y, 1.0f / d.z ); // bvh.cpp:275-276
