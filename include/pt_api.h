@@ -220,7 +220,8 @@ enum
     PT_K_CONNECT = 3, /* any-hit traversal:     BVH::Occluded,  src/bvh.cpp:270-310 */
     PT_K_FILM    = 4,
     PT_K_TONEMAP = 5,
-    PT_K_RESOLVE = 6, /* direct-light sum over the unoccluded shadow records, src/path_tracer.cpp:90-104 */
+    PT_K_RESOLVE = 6, /* direct-light sum over the unoccluded shadow records, src/path_tracer.cpp:90-104; not launched
+                         for a scene with one light and one sample per hit, where PT_K_CONNECT adds it */
     PT_K_COUNT   = 7
 };
 
