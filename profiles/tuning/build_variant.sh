@@ -1,8 +1,10 @@
 #!/bin/bash
 # Builds libptamd.so with extra -D tuning macros into variants/<name>.so (variants/ is not tracked; it ships to the
 # GPU box with the tree).  usage, from the repository root: profiles/tuning/build_variant.sh <name> "-DPT_LEAF_LANES=8 ..."
-# Macros: PT_EXTEND_REFILL_LANES, PT_CONNECT_REFILL_LANES, PT_LEAF_LANES, PT_TRAVERSE_BURST, PT_TRAVERSE_BLOCK,
-# PT_TRAVERSE_WAVES, PT_LDS_TOP_NODES (kernels.hip); PT_TOP_NODES is an environment variable read at upload.
+# Macros: PT_EXTEND_REFILL_LANES, PT_CONNECT_REFILL_LANES, PT_LEAF_LANES, PT_TRAVERSE_BURST, PT_LDS_TOP_NODES, and the
+# workgroup size / waves per SIMD of the three traversal instances: PT_TRIANGLE_BLOCK / PT_TRIANGLE_WAVES (closest hit,
+# scene without spheres), PT_TRAVERSE_BLOCK / PT_TRAVERSE_WAVES (closest hit with the sphere path), PT_CONNECT_BLOCK /
+# PT_CONNECT_WAVES (any hit) (kernels.hip); PT_TOP_NODES is an environment variable read at upload.
 mkdir -p variants
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -std=c++17 -O3 -fPIC -ffp-contract=off -fno-fast-math -Iinclude $2 -shared \
     -o variants/$1.so pathtracer_amd/csrc/api.hip pathtracer_amd/csrc/kernels.hip
