@@ -10,6 +10,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
+#include <memory>
 #include <new>
 #include <string>
 #include <vector>
@@ -30,6 +32,28 @@ int Fail( int code, const char* fmt, ... )
     va_end( ap );
     g_error = buf;
     return code;
+}
+
+// The C-ABI never lets an exception out (std::bad_alloc from the host-side staging vectors is the one that can
+// happen): every entry point is a function-try-block that ends here.
+int HostFailure( const char* where )
+{
+    try
+    {
+        throw;
+    }
+    catch ( const std::bad_alloc& )
+    {
+        return Fail( PT_ERR_DEVICE, "%s: out of host memory", where );
+    }
+    catch ( const std::exception& e )
+    {
+        return Fail( PT_ERR_DEVICE, "%s: %s", where, e.what() );
+    }
+    catch ( ... )
+    {
+        return Fail( PT_ERR_DEVICE, "%s: unknown exception", where );
+    }
 }
 
 #define HIP_TRY( expr )                                                                                                  \
@@ -542,6 +566,7 @@ extern "C" {
 const char* pt_last_error( void ) { return g_error.c_str(); }
 
 int pt_upload_scene( const PtSceneDesc* desc, PtScene** out )
+try
 {
     if ( !desc || !out ) return Fail( PT_ERR_INVALID_ARG, "pt_upload_scene: null argument" );
     *out = nullptr;
@@ -554,8 +579,8 @@ int pt_upload_scene( const PtSceneDesc* desc, PtScene** out )
     if ( desc->device < 0 || desc->device >= deviceCount ) return Fail( PT_ERR_DEVICE, "device %d requested, %d GPU(s) visible", desc->device, deviceCount );
     HIP_TRY( hipSetDevice( desc->device ) );
 
-    PtScene* s = new ( std::nothrow ) PtScene;
-    if ( !s ) return Fail( PT_ERR_DEVICE, "out of host memory" );
+    std::unique_ptr< PtScene > owner( new PtScene ); // freed on every early return and if anything below throws
+    PtScene* s = owner.get();
     s->device = desc->device;
     hipDeviceProp_t prop;
     if ( hipGetDeviceProperties( &prop, desc->device ) == hipSuccess && prop.multiProcessorCount > 0 ) s->gridBlocks = prop.multiProcessorCount * 8;
@@ -567,22 +592,19 @@ int pt_upload_scene( const PtSceneDesc* desc, PtScene** out )
         s->connectBlocks = connectPerCu * cus;
     }
     hipError_t e = hipStreamCreate( &s->stream );
-    if ( e != hipSuccess )
-    {
-        delete s;
-        return Fail( PT_ERR_DEVICE, "hipStreamCreate failed: %s", hipGetErrorString( e ) );
-    }
+    if ( e != hipSuccess ) return Fail( PT_ERR_DEVICE, "hipStreamCreate failed: %s", hipGetErrorString( e ) );
     rc = Upload( s, desc, escape );
-    if ( rc != PT_OK )
-    {
-        delete s;
-        return rc;
-    }
-    *out = s;
+    if ( rc != PT_OK ) return rc;
+    *out = owner.release();
     return PT_OK;
+}
+catch ( ... )
+{
+    return HostFailure( "pt_upload_scene" );
 }
 
 int pt_destroy_scene( PtScene* scene )
+try
 {
     if ( !scene ) return PT_OK;
     (void)hipSetDevice( scene->device );
@@ -590,8 +612,13 @@ int pt_destroy_scene( PtScene* scene )
     delete scene;
     return PT_OK;
 }
+catch ( ... )
+{
+    return HostFailure( "pt_destroy_scene" );
+}
 
 int pt_clear_film( PtScene* s )
+try
 {
     if ( !s ) return Fail( PT_ERR_INVALID_ARG, "pt_clear_film: null scene" );
     HIP_TRY( hipSetDevice( s->device ) );
@@ -605,8 +632,13 @@ int pt_clear_film( PtScene* s )
     s->rendered = false;
     return PT_OK;
 }
+catch ( ... )
+{
+    return HostFailure( "pt_clear_film" );
+}
 
 int pt_render( PtScene* s, const PtRenderParams* p )
+try
 {
     if ( !s || !p ) return Fail( PT_ERR_INVALID_ARG, "pt_render: null argument" );
     if ( p->struct_size != sizeof( PtRenderParams ) ) return Fail( PT_ERR_INVALID_ARG, "PtRenderParams::struct_size is %u, expected %zu", p->struct_size, sizeof( PtRenderParams ) );
@@ -727,8 +759,13 @@ int pt_render( PtScene* s, const PtRenderParams* p )
     s->renderMs += std::chrono::duration< double, std::milli >( std::chrono::steady_clock::now() - wallStart ).count();
     return PT_OK;
 }
+catch ( ... )
+{
+    return HostFailure( "pt_render" );
+}
 
 int pt_readback( PtScene* s, uint32_t tonemap, float* rgb_linear, float* rgb_tonemapped, PtStats* stats )
+try
 {
     if ( !s ) return Fail( PT_ERR_INVALID_ARG, "pt_readback: null scene" );
     if ( tonemap > PT_TONEMAP_NONE ) return Fail( PT_ERR_INVALID_ARG, "pt_readback: unknown tonemap operator %u", tonemap );
@@ -772,8 +809,13 @@ int pt_readback( PtScene* s, uint32_t tonemap, float* rgb_linear, float* rgb_ton
     }
     return PT_OK;
 }
+catch ( ... )
+{
+    return HostFailure( "pt_readback" );
+}
 
 int pt_film_device_ptr( PtScene* s, void** device_ptr, uint64_t* bytes )
+try
 {
     if ( !s || !device_ptr ) return Fail( PT_ERR_INVALID_ARG, "pt_film_device_ptr: null argument" );
     *device_ptr = s->film.ptr;
@@ -781,8 +823,13 @@ int pt_film_device_ptr( PtScene* s, void** device_ptr, uint64_t* bytes )
     s->rendered = true; // the caller may fill the film itself (merged films of several GPUs)
     return PT_OK;
 }
+catch ( ... )
+{
+    return HostFailure( "pt_film_device_ptr" );
+}
 
 int pt_download_film( PtScene* s, float* film_rgba )
+try
 {
     if ( !s || !film_rgba ) return Fail( PT_ERR_INVALID_ARG, "pt_download_film: null argument" );
     HIP_TRY( hipSetDevice( s->device ) );
@@ -790,8 +837,13 @@ int pt_download_film( PtScene* s, float* film_rgba )
     HIP_TRY( hipStreamSynchronize( s->stream ) );
     return PT_OK;
 }
+catch ( ... )
+{
+    return HostFailure( "pt_download_film" );
+}
 
 int pt_upload_film( PtScene* s, const float* film_rgba )
+try
 {
     if ( !s || !film_rgba ) return Fail( PT_ERR_INVALID_ARG, "pt_upload_film: null argument" );
     HIP_TRY( hipSetDevice( s->device ) );
@@ -800,9 +852,14 @@ int pt_upload_film( PtScene* s, const float* film_rgba )
     s->rendered = true;
     return PT_OK;
 }
+catch ( ... )
+{
+    return HostFailure( "pt_upload_film" );
+}
 
 int pt_trace_closest( PtScene* s, uint64_t n, const float* origins, const float* directions, int32_t* prim, float* t, float* u, float* v,
                       uint32_t* nodes_visited, uint32_t* prim_tests )
+try
 {
     if ( !s || ( n && ( !origins || !directions ) ) ) return Fail( PT_ERR_INVALID_ARG, "pt_trace_closest: null argument" );
     if ( n == 0 ) return PT_OK;
@@ -829,9 +886,14 @@ int pt_trace_closest( PtScene* s, uint64_t n, const float* origins, const float*
     if ( prim_tests ) HIP_TRY( hipMemcpy( prim_tests, dP.ptr, n * 4, hipMemcpyDeviceToHost ) );
     return PT_OK;
 }
+catch ( ... )
+{
+    return HostFailure( "pt_trace_closest" );
+}
 
 int pt_trace_any( PtScene* s, uint64_t n, const float* origins, const float* directions, const float* t_max, uint8_t* occluded,
                   uint32_t* nodes_visited, uint32_t* prim_tests )
+try
 {
     if ( !s || ( n && ( !origins || !directions || !t_max || !occluded ) ) ) return Fail( PT_ERR_INVALID_ARG, "pt_trace_any: null argument" );
     if ( n == 0 ) return PT_OK;
@@ -851,6 +913,10 @@ int pt_trace_any( PtScene* s, uint64_t n, const float* origins, const float* dir
     if ( nodes_visited ) HIP_TRY( hipMemcpy( nodes_visited, dN.ptr, n * 4, hipMemcpyDeviceToHost ) );
     if ( prim_tests ) HIP_TRY( hipMemcpy( prim_tests, dP.ptr, n * 4, hipMemcpyDeviceToHost ) );
     return PT_OK;
+}
+catch ( ... )
+{
+    return HostFailure( "pt_trace_any" );
 }
 
 } // extern "C"
