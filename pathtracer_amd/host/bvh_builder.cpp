@@ -3,6 +3,7 @@
 #include <atomic>
 #include <cstdlib>
 #include <stdexcept>
+#include <system_error>
 #include <thread>
 
 namespace pth
@@ -179,15 +180,29 @@ namespace
             const size_t second = slot + 2 * static_cast< size_t >( cutoff - start );
             node.offset         = static_cast< int32_t >( second );
             out.nodes[slot]     = node;
-            if ( count >= kParallelRange && freeThreads.fetch_sub( 1 ) > 0 )
+            if ( count >= kParallelRange )
             {
-                std::thread firstHalf( [=]() { Emit( start, cutoff, slot + 1 ); } );
-                Emit( cutoff, end, second );
-                firstHalf.join();
+                std::thread firstHalf;
+                if ( freeThreads.fetch_sub( 1 ) > 0 )
+                {
+                    try
+                    {
+                        firstHalf = std::thread( [=]() { Emit( start, cutoff, slot + 1 ); } );
+                    }
+                    catch ( const std::system_error& )
+                    {
+                        // no thread to be had: this one builds both halves
+                    }
+                }
+                if ( firstHalf.joinable() )
+                {
+                    Emit( cutoff, end, second );
+                    firstHalf.join();
+                    freeThreads.fetch_add( 1 );
+                    return;
+                }
                 freeThreads.fetch_add( 1 );
-                return;
             }
-            if ( count >= kParallelRange ) freeThreads.fetch_add( 1 );
             Emit( start, cutoff, slot + 1 );
             Emit( cutoff, end, second );
         }
