@@ -339,3 +339,31 @@ def test_single_light_direct_sum_equals_resolve_pass(name, keep, scenes, monkeyp
             films.append(lin)
     assert_bits_equal(films[0], films[1], "direct sum in the shadow-ray kernel vs separate pass")
     radiance_close(films[0], want / np.float32(8), f"{name}, light {keep} only")
+
+
+@pytest.mark.parametrize("name", ["cornell", "mixed"])
+def test_rays_on_box_planes_with_zero_direction_components(name, device_scenes):
+    """Origins exactly on node planes and directions with zero components: (plane - origin) * (1 / 0) is 0 * inf =
+    NaN in the slab test, which the reference's comparisons let pass (src/intersection_tests.cpp:91-110).  Hit,
+    t, u, v and the per-ray node and test counts must still equal the checker's."""
+    scene, dev, orc = device_scenes[name]
+    rng = np.random.default_rng(11)
+    n = 60_000
+    nodes = scene.nodes[rng.integers(0, len(scene.nodes), n)]
+    corner = np.where(rng.integers(0, 2, (n, 3)) == 1, nodes["aabb_max"], nodes["aabb_min"]).astype(np.float32)
+    lo, hi = scene.nodes["aabb_min"][0], scene.nodes["aabb_max"][0]
+    o = rng.uniform(lo - 0.25, hi + 0.25, (n, 3)).astype(np.float32)
+    on_plane = rng.integers(0, 2, (n, 3)) == 1          # some coordinates sit exactly on a plane of some node
+    o = np.where(on_plane, corner, o).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    zero = rng.integers(0, 3, (n, 3)) == 0               # a third of the components are +0 or -0
+    d = np.where(zero, np.where(rng.integers(0, 2, (n, 3)) == 1, np.float32(0.0), np.float32(-0.0)), d).astype(np.float32)
+    d[(d == 0).all(axis=1)] = np.float32([0, 0, 1])
+    got, want = dev.trace_closest(o, d), orc.intersect(o, d)
+    assert np.array_equal(got["prim"], want["prim"])
+    for k in ("t", "u", "v"):
+        assert_bits_equal(got[k], want[k], k)
+    assert np.array_equal(got["nodes"], want["nodes"]) and np.array_equal(got["prim_tests"], want["prim_tests"])
+    tmax = rng.uniform(0, 3, n).astype(np.float32)
+    got, want = dev.trace_any(o, d, tmax), orc.occluded(o, d, tmax)
+    assert np.array_equal(got["occluded"], want["occluded"]) and np.array_equal(got["nodes"], want["nodes"])
