@@ -23,7 +23,7 @@ def scenes():
 
 @pytest.fixture(scope="session")
 def golden():
-    return {name: dict(np.load(os.path.join(GOLDEN, f"golden_{name}.npz"))) for name in ("cornell", "mixed", "leaf", "bvh")}
+    return {name: dict(np.load(os.path.join(GOLDEN, f"golden_{name}.npz"))) for name in ("cornell", "mixed", "leaf", "bvh", "converged")}
 
 
 @pytest.fixture(scope="session")

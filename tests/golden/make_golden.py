@@ -16,6 +16,7 @@ Files written:
                       sample-table run, closest-hit and any-hit results on seeded ray batches
   golden_leaf.npz     known-answer tables of the leaf functions incl. edge cases
   golden_bvh.npz      node arrays the reference's BVH::Build produces for the three split methods
+  golden_converged.npz  64x64 mean radiance of the reference's Li over 8192 samples per pixel, both scenes
 """
 import os
 import sys
@@ -193,15 +194,33 @@ def golden_bvh(scenes):
     np.savez_compressed(os.path.join(HERE, "golden_bvh.npz"), **out)
 
 
+CONVERGED_SPP, CONVERGED_SEED, CONVERGED_SIZE = 8192, 2024, 64
+
+
+def golden_converged(scenes):
+    """Mean radiance per pixel of the reference's Li over many samples: what a render has to converge to."""
+    out = {"spp": np.array([CONVERGED_SPP], np.int64), "seed": np.array([CONVERGED_SEED], np.int64)}
+    for name, scene in scenes.items():
+        rs = ref.RefScene(scene.with_image(CONVERGED_SIZE, CONVERGED_SIZE).to_desc())
+        img, _ = rs.li_image(CONVERGED_SPP, seed=CONVERGED_SEED)
+        out[f"{name}_mean"] = (img / np.float32(CONVERGED_SPP)).astype(np.float32)
+        print(name, "converged mean per channel", out[f"{name}_mean"].reshape(-1, 3).mean(axis=0))
+    np.savez_compressed(os.path.join(HERE, "golden_converged.npz"), **out)
+
+
 def main():
     if not ref.available():
         sys.exit("oracle/_ref/libptref.so is missing: run `make ref` in the container that holds /root/reference")
     scenes = make_scenes()
+    if "--only-converged" in sys.argv:   # the other files stay as they are
+        golden_converged(scenes)
+        return
     for name, scene in scenes.items():
         scene.save(os.path.join(HERE, f"{name}_scene.npz"))
         golden_for(name, scene)
     golden_leaf()
     golden_bvh(scenes)
+    golden_converged(scenes)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")

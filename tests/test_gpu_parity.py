@@ -367,3 +367,24 @@ def test_rays_on_box_planes_with_zero_direction_components(name, device_scenes):
     tmax = rng.uniform(0, 3, n).astype(np.float32)
     got, want = dev.trace_any(o, d, tmax), orc.occluded(o, d, tmax)
     assert np.array_equal(got["occluded"], want["occluded"]) and np.array_equal(got["nodes"], want["nodes"])
+
+
+@pytest.mark.parametrize("name", ["cornell", "mixed"])
+def test_converges_to_the_reference_renderer(name, scenes, golden):
+    """32768 samples per pixel on the GPU (its own seed) against the mean of 8192 samples per pixel of the
+    reference's own code (tests/golden/golden_converged.npz): every channel's image mean within 1 %, and the
+    picture itself within a few percent pixel by pixel (what is left is the noise of the 8192-sample estimate)."""
+    want = golden["converged"][f"{name}_mean"].astype(np.float64)
+    size = want.shape[0]
+    with api.DeviceScene(scenes[name].with_image(size, size).to_desc()) as dev:
+        dev.render(32768, seed=4242)
+        lin, _, stats = dev.readback()
+    assert stats.samples == size * size * 32768
+    got = lin.astype(np.float64)
+    for c in range(3):
+        a, b = got[..., c].mean(), want[..., c].mean()
+        print(f"{name} channel {c}: gpu {a:.6f}, reference {b:.6f}, {100 * (a / b - 1):+.3f} %")
+        assert abs(a - b) <= 0.01 * b
+    rel = np.abs(got - want) / (want + 0.02)
+    print(f"{name}: mean per-pixel deviation {100 * rel.mean():.3f} %, 99th percentile {100 * np.percentile(rel, 99):.3f} %")
+    assert rel.mean() < 0.02 and np.percentile(rel, 99) < 0.10
