@@ -620,7 +620,7 @@ __device__ __forceinline__ void FlushWaveCounter( uint64_t* stats, int slot, uin
 #ifndef PT_TRAVERSE_BURST
 #define PT_TRAVERSE_BURST 3
 #endif
-// The traversal kernels keep the first kLdsTopNodes nodes of the (breadth-first ordered) node array in LDS, one copy
+// The traversal kernels keep the first kLdsTopNodes nodes of the node array (the top of the tree, most visited boxes first) in LDS, one copy
 // per workgroup, and read them with ds_read instead of going through the texture addresser and the L1 - the
 // busiest unit of these kernels.  Large workgroups share one copy between more waves: two workgroups per CU,
 // 2,400 nodes = 75 KB each; 768 threads (6 waves per SIMD) at 80 VGPRs, 1,024 threads (8 waves per SIMD) at 64.  Measured, extend per launch of

@@ -3,7 +3,7 @@
 // All scene data is rewritten at upload into layouts chosen for 16-byte coalescable loads:
 //   nodes      2 x float4 per node (32 B): {lo.x, lo.y, hi.x, hi.y} {lo.z, hi.z, link, word}; link = node to go to after
 //              this node's subtree (top bit: leaf), word = leaf descriptor or first child.  The first numTopNodes
-//              nodes are the top of the tree in breadth-first order, the rest follows in the reference's pre-order
+//              nodes are the top of the tree (sibling pairs, largest parent box first), the rest follows in the reference's pre-order
 //   prims      4 x float4 per primitive (48 B used, 64 B apart = one cache line): triangle {v0, tag 0} {v1 - v0} {v2 - v0};
 //              sphere {centre, tag 1} {radius, sphere index}
 //   triShade   8 x float4 per triangle primitive (112 B used, 128 B apart = one L2 line): n0 n1 n2 t0 t1 t2 uv0 uv1 uv2 material
@@ -21,7 +21,7 @@ namespace ptd
 
 constexpr uint32_t kInnerNode    = 0xFFFFFFFFu; // "no leaf pending" in the traversal state; never a valid leaf word
 constexpr uint32_t kLeafFlag     = 0x80000000u; // top bit of a node's link word
-constexpr uint32_t kTopNodes     = 4095;          // default size of the breadth-first ordered top of the tree
+constexpr uint32_t kTopNodes     = 4095;          // default size of the top of the tree that is stored first
 constexpr uint32_t kLeafFirstMask = 0x0FFFFFFFu; // leaf word: low 28 bits first primitive, high 4 bits count - 1
 constexpr int kMaxLeafShapes     = 16;
 // nodes and primitive records are read through 32-bit-offset buffer descriptors: each array stays under 4 GiB
