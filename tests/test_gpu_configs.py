@@ -98,6 +98,14 @@ def test_atrium_primary_and_shadow_ray_batches(atrium):
     assert np.array_equal(got["nodes"], want["nodes"])
 
 
+def test_cornell_512_16spp(scenes):
+    """The first configuration of the list (512 x 512, 16 spp, depth 5; the reference runs it on the CPU): the
+    same samples on the GPU, against the checker."""
+    desc = scenes["cornell"].with_image(512, 512).to_desc()
+    with api.DeviceScene(desc) as dev:
+        check_against_oracle(dev, checker.OracleScene(desc), 16, 16, "cornell 512^2 16 spp")
+
+
 def test_cornell_1024_deterministic_and_converged(scenes):
     """Cornell box at 1024x1024: 4 spp against the checker sample for sample, then 1024 spp against the mean of
     the checker's 64 spp (different sample sets of the same estimator): per-channel image mean within 1 %."""

@@ -131,3 +131,17 @@ def test_benchmark_scene_bit_identical_to_reference_li():
         assert_bits_equal(a["t"], b["t"], "t")
         assert np.array_equal(a["nodes"], b["nodes"]) and np.array_equal(a["prim_tests"], b["prim_tests"])
         rs.close()
+
+
+def test_cornell_512_16spp_cpu_configuration(scenes):
+    """The CPU-only configuration of the benchmark list: resources/scenes/cornell.json at 512 x 512, 16 samples
+    per pixel, depth 5 (4.19 M pixel samples), the reference's own code against the checker, bit for bit."""
+    scene = scenes["cornell"].with_image(512, 512)
+    assert scene.max_depth == 5
+    desc = scene.to_desc()
+    want, rays = ref.RefScene(desc).li_image(16, seed=16)
+    got, stats = checker.OracleScene(desc).li_image(16, seed=16)
+    assert_bits_equal(got, want, "radiance sums")
+    assert stats["samples"] == 512 * 512 * 16
+    assert stats["rays_closest"] == rays["rays_closest"] and stats["rays_shadow"] == rays["rays_shadow"]
+    assert 0.05 < float(got.mean()) / 16 < 1.0
