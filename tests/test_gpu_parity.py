@@ -388,3 +388,63 @@ def test_converges_to_the_reference_renderer(name, scenes, golden):
     rel = np.abs(got - want) / (want + 0.02)
     print(f"{name}: mean per-pixel deviation {100 * rel.mean():.3f} %, 99th percentile {100 * np.percentile(rel, 99):.3f} %")
     assert rel.mean() < 0.02 and np.percentile(rel, 99) < 0.10
+
+
+def mutated_scene(base, seed):
+    """A variation of a fixture scene with a random mix of features: several point / directional lights, area
+    lights on triangles and on spheres with 1-3 samples each, emissive materials, a cube map or a constant
+    background, depth 1-6.  Geometry and BVH stay the fixture's."""
+    rng = np.random.default_rng(seed)
+    s = base.with_image(36, 28, 36 / 28)
+    s.max_depth = int(rng.integers(1, 7))
+    s.materials = s.materials.copy()
+    for m in range(len(s.materials)):
+        if rng.uniform() < 0.4:
+            s.materials["Ke"][m] = rng.uniform(0, 3, 3).astype(np.float32)
+    lights = []
+
+    def light(kind, **kw):
+        rec = np.zeros(1, abi.LIGHT_DTYPE)
+        rec["type"], rec["n_samples"], rec["prim"] = kind, 1, -1
+        rec["Lemit"] = rng.uniform(0.5, 20, 3).astype(np.float32)
+        for k, v in kw.items():
+            rec[k] = v
+        lights.append(rec)
+
+    lo, hi = s.nodes["aabb_min"][0], s.nodes["aabb_max"][0]
+    for _ in range(int(rng.integers(0, 3))):
+        light(abi.PT_LIGHT_POINT, position=rng.uniform(lo, hi).astype(np.float32))
+    for _ in range(int(rng.integers(0, 3))):
+        d = rng.normal(size=3).astype(np.float32)
+        light(abi.PT_LIGHT_DIRECTIONAL, direction=d / np.float32(np.linalg.norm(d)))
+    for prim in rng.choice(len(s.prims), size=int(rng.integers(0, 4)), replace=False):
+        light(abi.PT_LIGHT_AREA, prim=int(prim), n_samples=int(rng.integers(1, 4)))
+    spheres = np.flatnonzero(s.prims["type"] == abi.PT_PRIM_SPHERE)
+    if len(spheres) and rng.uniform() < 0.7:
+        light(abi.PT_LIGHT_AREA, prim=int(rng.choice(spheres)), n_samples=int(rng.integers(1, 3)))
+    rng.shuffle(lights)
+    s.lights = np.concatenate(lights) if lights else np.zeros(0, abi.LIGHT_DTYPE)
+    if rng.uniform() < 0.5:
+        n = int(rng.integers(1, 9))
+        s.skybox_width = s.skybox_height = n
+        sky = rng.uniform(0, 1, (6, n, n, 4)).astype(np.float32)
+        s.skybox = (np.floor(sky * 255) / np.float32(255)).astype(np.float32).reshape(-1)
+    else:
+        s.background_radiance = rng.uniform(0, 1, 3).astype(np.float32)
+    return s
+
+
+@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("name", ["cornell", "mixed"])
+def test_random_feature_mixes_match_the_checker(name, seed, scenes):
+    scene = mutated_scene(scenes[name], 1000 * seed + len(name))
+    desc = scene.to_desc()
+    with api.DeviceScene(desc) as dev:
+        dev.render(6, seed=seed)
+        lin, _, stats = dev.readback()
+    want, ostats = checker.OracleScene(desc).li_image(6, seed=seed)
+    what = f"{name} variation {seed}: depth {scene.max_depth}, {len(scene.lights)} lights, {'cube map' if scene.skybox_width else 'background'}"
+    radiance_close(lin, want / np.float32(6), what)
+    for c in ("rays_closest", "nodes_closest", "tri_tests_closest", "sphere_tests_closest", "shaded_hits", "samples"):
+        assert getattr(stats, c) == ostats[c], c
+    assert stats.rays_shadow <= ostats["rays_shadow"]

@@ -145,3 +145,20 @@ def test_cornell_512_16spp_cpu_configuration(scenes):
     assert stats["samples"] == 512 * 512 * 16
     assert stats["rays_closest"] == rays["rays_closest"] and stats["rays_shadow"] == rays["rays_shadow"]
     assert 0.05 < float(got.mean()) / 16 < 1.0
+
+
+@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("name", ["cornell", "mixed"])
+def test_random_feature_mixes_bit_identical_to_reference_li(name, seed, scenes):
+    """The scene variations of the GPU parity test (several point / directional lights, area lights on triangles
+    and spheres with 1-3 samples, emissive materials, depth 1-6) through the reference's own Li.  The cube map is
+    replaced by a constant background here: the reference's Skybox does not build in this container."""
+    from test_gpu_parity import mutated_scene
+    scene = mutated_scene(scenes[name], 1000 * seed + len(name))
+    scene.skybox, scene.skybox_width, scene.skybox_height = np.zeros(0, np.float32), 0, 0
+    scene.background_radiance = np.float32([0.3, 0.2, 0.1])
+    desc = scene.to_desc()
+    want, rays = ref.RefScene(desc).li_image(5, seed=seed)
+    got, stats = checker.OracleScene(desc).li_image(5, seed=seed)
+    assert_bits_equal(got, want, "radiance")
+    assert stats["rays_closest"] == rays["rays_closest"] and stats["rays_shadow"] == rays["rays_shadow"]
