@@ -1,0 +1,94 @@
+"""Triangle sets that stress the traversal's tie-breaking and rounding: coincident triangles (equal t: the first
+in primitive order keeps the hit), shared edges and vertices, zero-area triangles (rejected by the determinant
+test), axis-aligned triangles (boxes of zero thickness), very large and very small coordinates (small enough for the
+determinant threshold to matter).  Built into a
+complete scene with this repository's host BVH builder; used by the CPU and GPU parity tests."""
+import numpy as np
+
+from pathtracer_amd import abi, host
+from pathtracer_amd.scene import SceneData
+
+
+def triangle_scene(tris, split_method=abi.PTH_SPLIT_SAH):
+    """tris: (n, 3, 3) float32 vertex positions -> SceneData with flat normals, one grey material, a BVH."""
+    tris = np.ascontiguousarray(tris, np.float32)
+    n = len(tris)
+    s = SceneData()
+    s.vertices = tris.reshape(-1, 3).copy()
+    e1, e2 = tris[:, 1] - tris[:, 0], tris[:, 2] - tris[:, 0]
+    nrm = np.cross(e1, e2).astype(np.float32)
+    length = np.linalg.norm(nrm, axis=1, keepdims=True)
+    nrm = np.where(length > 0, nrm / np.maximum(length, np.float32(1e-30)), np.float32([0, 1, 0])).astype(np.float32)
+    s.normals = np.repeat(nrm, 3, axis=0)
+    tan = e1 / np.maximum(np.linalg.norm(e1, axis=1, keepdims=True), np.float32(1e-30))
+    tan = np.where(np.isfinite(tan).all(axis=1, keepdims=True) & (np.abs(tan).sum(axis=1, keepdims=True) > 0), tan, np.float32([1, 0, 0]))
+    s.tangents = np.repeat(tan.astype(np.float32), 3, axis=0)
+    s.uvs = np.zeros((3 * n, 2), np.float32)
+    s.meshes = np.zeros(1, abi.MESH_DTYPE)
+    s.meshes["num_vertices"], s.meshes["material"] = 3 * n, 0
+    s.materials = np.zeros(1, abi.MATERIAL_DTYPE)
+    s.materials["albedo"], s.materials["albedo_texture"] = np.float32([0.7, 0.7, 0.7]), -1
+    boxes = np.concatenate([tris.min(axis=1), tris.max(axis=1)], axis=1)
+    nodes, order = host.build_bvh(boxes, split_method)
+    s.nodes = nodes
+    s.triangles = np.zeros(n, abi.TRIANGLE_DTYPE)
+    s.triangles["i0"], s.triangles["i1"], s.triangles["i2"] = 3 * np.arange(n), 3 * np.arange(n) + 1, 3 * np.arange(n) + 2
+    s.prims = np.zeros(n, abi.PRIM_DTYPE)
+    s.prims["type"], s.prims["index"] = abi.PT_PRIM_TRIANGLE, order     # primitive k of the tree is shape order[k]
+    s.image_width = s.image_height = 24
+    s.camera["aspect_ratio"] = np.float32(1)
+    lo, hi = s.vertices.min(axis=0), s.vertices.max(axis=0)
+    extent = np.float32(max(float((hi - lo).max()), 1e-6))
+    s.camera["position"] = (np.float32(0.5) * (lo + hi) + np.float32([0, 0, 1.6]) * extent).astype(np.float32)   # looks down -z at the set
+    s.background_radiance = np.float32([0.5, 0.6, 0.7])   # the only light: paths that escape carry it back
+    return s
+
+
+def cases(seed=0):
+    """name -> (SceneData, ray origins, ray directions)"""
+    rng = np.random.default_rng(seed)
+    out = {}
+
+    def rays_towards(points, n, spread):
+        target = points[rng.integers(0, len(points), n)] + rng.normal(scale=spread, size=(n, 3))
+        o = target + rng.normal(size=(n, 3)) * (np.abs(points).max() * 0.5 + 1)
+        return o.astype(np.float32), (target - o).astype(np.float32)
+
+    # a grid of quads: every interior edge and vertex is shared, all triangles coplanar and axis-aligned
+    g = 12
+    xs, ys = np.meshgrid(np.arange(g, dtype=np.float32), np.arange(g, dtype=np.float32))
+    p = np.stack([xs, ys, np.zeros_like(xs)], axis=-1)
+    quads = np.stack([p[:-1, :-1], p[:-1, 1:], p[1:, 1:], p[1:, :-1]], axis=2).reshape(-1, 4, 3)
+    grid = np.concatenate([quads[:, [0, 1, 2]], quads[:, [0, 2, 3]]])
+    n = 40_000
+    o = np.stack([rng.integers(0, g, n), rng.integers(0, g, n), np.full(n, 5)], axis=1).astype(np.float32)   # aimed at vertices
+    o[n // 2:, :2] += rng.choice([0.0, 0.5, 0.25], size=(n - n // 2, 2)).astype(np.float32)                    # and at edges
+    d = np.tile(np.float32([0, 0, -1]), (n, 1))
+    d[::3] += rng.normal(scale=0.3, size=(len(d[::3]), 3)).astype(np.float32)
+    out["shared edges and vertices"] = (triangle_scene(grid), o, d)
+
+    # every triangle three times, shuffled: equal t from different primitives
+    base = rng.uniform(-1, 1, (300, 1, 3)) + rng.uniform(-0.3, 0.3, (300, 3, 3))
+    dup = np.concatenate([base, base, base])[rng.permutation(900)]
+    o, d = rays_towards(base.reshape(-1, 3), n, 0.05)
+    out["coincident triangles"] = (triangle_scene(dup), o, d)
+
+    # zero-area triangles among ordinary ones: two equal vertices, three collinear vertices
+    good = rng.uniform(-1, 1, (200, 1, 3)) + rng.uniform(-0.3, 0.3, (200, 3, 3))
+    line = rng.uniform(-1, 1, (100, 1, 3)) + rng.uniform(-0.3, 0.3, (100, 1, 3)) * np.float32([[[0.0], [0.5], [1.0]]])
+    twice = good[:100].copy()
+    twice[:, 2] = twice[:, 1]
+    mix = np.concatenate([good, line, twice])[rng.permutation(400)]
+    o, d = rays_towards(mix.reshape(-1, 3), n, 0.02)
+    out["zero-area triangles"] = (triangle_scene(mix), o, d)
+
+    # the same soup a million units away and a millionth of the size: rounding in the slab and triangle tests
+    soup = rng.uniform(-1, 1, (500, 1, 3)) + rng.uniform(-0.2, 0.2, (500, 3, 3))
+    far = (soup * 100 + np.float32([1e6, -2e6, 5e5])).astype(np.float32)
+    o, d = rays_towards(far.reshape(-1, 3), n, 5.0)
+    out["coordinates around 1e6"] = (triangle_scene(far), o, d)
+    # small enough for the determinant threshold (fabs(det) < 1e-9, src/intersection_tests.cpp:41) to reject part of them
+    tiny = (soup * 2e-4).astype(np.float32)
+    o, d = rays_towards(tiny.reshape(-1, 3), n, 1e-5)
+    out["coordinates around 1e-4"] = (triangle_scene(tiny), o.astype(np.float32), d.astype(np.float32))
+    return out

@@ -162,3 +162,28 @@ def test_random_feature_mixes_bit_identical_to_reference_li(name, seed, scenes):
     got, stats = checker.OracleScene(desc).li_image(5, seed=seed)
     assert_bits_equal(got, want, "radiance")
     assert stats["rays_closest"] == rays["rays_closest"] and stats["rays_shadow"] == rays["rays_shadow"]
+
+
+def test_tie_breaking_and_rounding_cases_bit_identical_to_reference():
+    """Coincident triangles, shared edges and vertices, zero-area triangles, very large and very small
+    coordinates (tests/geometry_cases.py): hit primitive, t, u, v and the per-ray counts of the reference's
+    BVH::Intersect / Occluded against the checker's."""
+    from geometry_cases import cases
+    for what, (scene, o, d) in cases().items():
+        desc = scene.to_desc()
+        want, got = ref.RefScene(desc).intersect(o, d), checker.OracleScene(desc).intersect(o, d)
+        hit = want["prim"] >= 0
+        print(f"{what}: {len(scene.prims)} triangles, {hit.mean():.2f} of the rays hit")
+        assert hit.mean() > 0.05, what
+        assert np.array_equal(got["prim"], want["prim"]), what
+        for key in ("t", "nodes", "prim_tests"):
+            assert_bits_equal(got[key], want[key], f"{what}: {key}")
+        for key in ("u", "v"):
+            assert_bits_equal(got[key][hit], want[key][hit], f"{what}: {key}")
+        tmax = np.where(hit, np.minimum(want["t"], np.float32(1e30)) * np.float32(1.5), np.float32(10)).astype(np.float32)
+        tmax[::2] = want["t"][::2]        # exactly the hit distance: strict < must not report the hit itself
+        assert np.array_equal(checker.OracleScene(desc).occluded(o, d, tmax)["occluded"], ref.RefScene(desc).occluded(o, d, tmax)), what
+        img_ref, _ = ref.RefScene(desc).li_image(3, seed=5)      # paths bouncing between these triangles under a constant sky
+        img, _ = checker.OracleScene(desc).li_image(3, seed=5)
+        assert_bits_equal(img, img_ref, f"{what}: radiance")
+        assert img.mean() > 0.01, what
