@@ -37,6 +37,7 @@ def lib():
         L.pth_camera_vectors.argtypes = [C.c_void_p] * 4
         L.pth_sphere_world_to_local.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
         L.pth_write_image.argtypes = [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32]
+        L.pth_read_image.argtypes = [C.c_char_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_void_p, C.c_uint64]
         L.pth_last_error.restype = C.c_char_p
         _LIB = L
     return _LIB
@@ -145,6 +146,15 @@ def sphere_world_to_local(position, rotation_rad, radius):
     out = np.zeros(16, np.float32)
     _check(lib().pth_sphere_world_to_local(p.ctypes.data, r.ctypes.data, float(radius), out.ctypes.data))
     return out
+
+
+def read_image(filename, flip=True):
+    """RGBA8 pixels (h, w, 4) as Texture::Load decodes them (src/resource/texture.cpp:19-33)."""
+    w, h = C.c_int32(0), C.c_int32(0)
+    _check(lib().pth_read_image(filename.encode(), int(flip), C.byref(w), C.byref(h), None, 0))
+    px = np.zeros((h.value, w.value, 4), np.uint8)
+    _check(lib().pth_read_image(filename.encode(), int(flip), C.byref(w), C.byref(h), px.ctypes.data, px.nbytes))
+    return px
 
 
 def write_image(filename, rgb):

@@ -202,6 +202,24 @@ int pth_write_image( const char* filename, const float* rgb, int32_t width, int3
     } );
 }
 
+int pth_read_image( const char* filename, int32_t flip_vertically, int32_t* width, int32_t* height, uint8_t* rgba, uint64_t capacity )
+{
+    if ( !filename || !width || !height ) return Fail( "pth_read_image: bad argument" );
+    return Guard( [&] {
+        pth::ImageRGBA8 img;
+        std::string err;
+        if ( !pth::ReadImageRGBA8( filename, flip_vertically != 0, img, err ) ) return Fail( err );
+        *width  = img.width;
+        *height = img.height;
+        if ( rgba )
+        {
+            if ( capacity < img.pixels.size() ) return Fail( "pth_read_image: buffer too small" );
+            std::memcpy( rgba, img.pixels.data(), img.pixels.size() );
+        }
+        return 0;
+    } );
+}
+
 const char* pth_last_error( void ) { return g_error.c_str(); }
 
 } // extern "C"

@@ -187,3 +187,97 @@ def test_tie_breaking_and_rounding_cases_bit_identical_to_reference():
         img, _ = checker.OracleScene(desc).li_image(3, seed=5)
         assert_bits_equal(img, img_ref, f"{what}: radiance")
         assert img.mean() > 0.01, what
+
+
+def test_tga_decoding_equals_the_reference_texture_load():
+    """Every TGA the reference ships (the Sponza textures: 24 and 32 bit, run-length encoded and plain), decoded
+    by the host library and by the reference's Texture::Load (stb_image), flipped and unflipped: equal bytes."""
+    import glob
+    files = sorted(glob.glob("/root/reference/resources/**/*.tga", recursive=True))
+    assert len(files) >= 30
+    for f in files:
+        for flip in (True, False):
+            mine, theirs = host.read_image(f, flip), ref.load_texture(f, flip=flip)
+            assert mine.shape == theirs.shape and np.array_equal(mine, theirs), (f, flip)
+
+
+def test_jpeg_decoding_equals_the_reference_texture_load(tmp_path):
+    """Baseline JPEG through the host library and through the reference's Texture::Load (stb_image): the seven
+    files the reference ships (4:2:0) and generated ones - 4:4:4, 4:2:2, 4:2:0, grey, odd sizes down to 1 x 1,
+    qualities 5 to 100, optimised Huffman tables, restart markers - equal bytes.  A progressive file is refused
+    with an error (the reference would decode it; none of its scenes has one)."""
+    import glob
+    files = sorted(glob.glob("/root/reference/resources/**/*.jpg", recursive=True))
+    assert len(files) >= 7
+    PIL = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(8)
+    yy, xx = np.mgrid[0:97, 0:131]
+    smooth = np.stack([128 + 120 * np.sin(xx / 9.0) * np.cos(yy / 7.0), 128 + 100 * np.cos(xx / 5.0 + yy / 11.0), (xx * 2 + yy) % 256], axis=-1)
+    pictures = {"smooth": smooth, "noise": rng.integers(0, 256, (97, 131, 3)), "edges": (rng.integers(0, 2, (97, 131, 3)) * 255)}
+    n = 0
+    for name, pic in pictures.items():
+        pic = np.clip(pic, 0, 255).astype(np.uint8)
+        for (w, h) in ((131, 97), (64, 64), (17, 9), (8, 8), (1, 1), (33, 1), (1, 20)):
+            img = PIL.fromarray(pic[:h, :w])
+            for subsampling in (0, 1, 2):
+                for quality, extra in ((75, {}), (100, {}), (5, {}), (90, {"optimize": True}), (60, {"restart_marker_blocks": 3})):
+                    f = str(tmp_path / f"c{n}.jpg")
+                    n += 1
+                    img.save(f, "JPEG", quality=quality, subsampling=subsampling, **extra)
+                    files.append(f)
+            f = str(tmp_path / f"g{n}.jpg")
+            n += 1
+            img.convert("L").save(f, "JPEG", quality=80)
+            files.append(f)
+    for f in files:
+        for flip in (True, False):
+            mine, theirs = host.read_image(f, flip), ref.load_texture(f, flip=flip)
+            assert mine.shape == theirs.shape and np.array_equal(mine, theirs), (f, flip)
+    f = str(tmp_path / "progressive.jpg")
+    PIL.fromarray(pictures["smooth"].clip(0, 255).astype(np.uint8)).save(f, "JPEG", progressive=True)
+    with pytest.raises(host.HostError):
+        host.read_image(f, True)
+
+
+def test_reference_texture_scene_loads_and_renders_bit_identically():
+    """resources/scenes/texture.json (a sphere, a textured plane, the JPEG texture the reference ships) through
+    the host loader: the texel pool equals the reference's decode, and the reference's Li over the flattened
+    scene equals the checker's."""
+    res = "/root/reference/resources/"
+    with host.HostScene.from_file(res + "scenes/texture.json", res) as hs:
+        scene = hs.to_data()
+    assert len(scene.textures) == 1 and (int(scene.textures["width"][0]), int(scene.textures["height"][0])) == (220, 220)
+    assert np.array_equal(scene.texels.reshape(220, 220, 4), ref.load_texture(res + "images/cockatoo.jpg", flip=True))
+    # As shipped the file renders black: its light uses the stale key "color" and stays dark, and its sphere's
+    # "transform" block is not a key of the parser, so the unit sphere sits around the camera.  Give the light
+    # power and move the camera out to compare something; then the file as it is.
+    lit = scene.with_image(64, 64)
+    lit.lights = lit.lights.copy()
+    lit.lights["Lemit"][0] = np.float32([3, 3, 3])
+    lit.camera["position"] = np.float32([0, 0.5, 4])
+    for s, nonzero in ((lit, True), (scene.with_image(64, 64), False)):
+        desc = s.to_desc()
+        want, rays = ref.RefScene(desc).li_image(4, seed=12)
+        got, stats = checker.OracleScene(desc).li_image(4, seed=12)
+        assert_bits_equal(got, want, "radiance")
+        assert stats["rays_closest"] == rays["rays_closest"] and (got.mean() > 0.01) == nonzero
+
+
+def test_cube_map_faces_from_the_reference_files(tmp_path):
+    """The water cube map of resources/scenes/dragon.json (six 2048 x 2048 JPEG files): the host loader's float4
+    faces equal byte / 255 of the reference's decode (stbi_loadf with gamma and scale 1, src/resource/skybox.cpp:34-37),
+    in the face order right, left, top, bottom, back, front."""
+    res = "/root/reference/resources/"
+    scene_file = tmp_path / "sky.json"
+    scene_file.write_text('''{ "Skybox": { "name": "water", "right": "images/water/right.jpg", "left": "images/water/left.jpg",
+      "top": "images/water/top.jpg", "bottom": "images/water/bottom.jpg", "back": "images/water/back.jpg",
+      "front": "images/water/front.jpg", "flipVertically": false },
+      "Material": { "name": "grey", "albedo": [ 0.5, 0.5, 0.5 ] },
+      "Sphere": { "material": "grey", "position": [ 0, 0, -5 ], "radius": 1 } }''')
+    with host.HostScene.from_file(str(scene_file), res) as hs:
+        scene = hs.to_data()
+    assert (scene.skybox_width, scene.skybox_height) == (2048, 2048)
+    faces = scene.skybox.reshape(6, 2048, 2048, 4)
+    for k, name in enumerate(("right", "left", "top", "bottom", "back", "front")):
+        want = ref.load_texture(res + f"images/water/{name}.jpg", flip=False).astype(np.float32) / np.float32(255)
+        assert np.array_equal(faces[k], want), name
