@@ -9,7 +9,7 @@
 //     end samples from the vertical sums alone;
 //   * YCbCr to RGB in 20-bit fixed point whose factors are first rounded to 12 bits, with the Cb term of green
 //     truncated to its upper 16 bits before the sum.
-// Pinned against the reference's own decode of every JPEG file it ships (tests/test_oracle_vs_reference.py).
+// The tests compare with the reference's own decode of every JPEG file it ships and of generated files.
 #include "image_io.hpp"
 
 #include <cstring>
