@@ -45,31 +45,32 @@ namespace
         std::vector< uint8_t > plane;
     };
 
-    uint8_t Clamp8( int x ) { return x < 0 ? 0 : ( x > 255 ? 255 : static_cast< uint8_t >( x ) ); }
+    uint8_t Clamp8( long long x ) { return x < 0 ? 0 : ( x > 255 ? 255 : static_cast< uint8_t >( x ) ); }
 
     // 13-bit constants of the slow integer DCT
-    constexpr int Fixed( double x ) { return static_cast< int >( x * 4096 + 0.5 ); }
+    constexpr long long Fixed( double x ) { return static_cast< int >( x * 4096 + 0.5 ); }
 
-    // one dimension of the inverse transform on s[0..7]; leaves the even part in x[0..3] and the odd part in t[0..3],
-    // both scaled by 4096, for the caller to combine, bias and shift
-    inline void InverseDct1D( const int s[8], int x[4], int t[4] )
+    // One dimension of the inverse transform on s[0..7]; leaves the even part in x[0..3] and the odd part in t[0..3],
+    // both scaled by 4096, for the caller to combine, bias and shift.  32 bits hold every intermediate of a valid
+    // file; 64 are used so that the coefficients of a damaged one cannot overflow.
+    inline void InverseDct1D( const int s[8], long long x[4], long long t[4] )
     {
-        int p2 = s[2], p3 = s[6];
-        int p1 = ( p2 + p3 ) * Fixed( 0.5411961f );
-        const int t2e = p1 + p3 * Fixed( -1.847759065f );
-        const int t3e = p1 + p2 * Fixed( 0.765366865f );
-        const int t0e = ( s[0] + s[4] ) * 4096;
-        const int t1e = ( s[0] - s[4] ) * 4096;
+        long long p2 = s[2], p3 = s[6];
+        long long p1 = ( p2 + p3 ) * Fixed( 0.5411961f );
+        const long long t2e = p1 + p3 * Fixed( -1.847759065f );
+        const long long t3e = p1 + p2 * Fixed( 0.765366865f );
+        const long long t0e = ( static_cast< long long >( s[0] ) + s[4] ) * 4096;
+        const long long t1e = ( static_cast< long long >( s[0] ) - s[4] ) * 4096;
         x[0] = t0e + t3e;
         x[3] = t0e - t3e;
         x[1] = t1e + t2e;
         x[2] = t1e - t2e;
-        int t0 = s[7], t1 = s[5], t2 = s[3], t3 = s[1];
-        p3      = t0 + t2;
-        int p4  = t1 + t3;
-        p1      = t0 + t3;
-        p2      = t1 + t2;
-        const int p5 = ( p3 + p4 ) * Fixed( 1.175875602f );
+        long long t0 = s[7], t1 = s[5], t2 = s[3], t3 = s[1];
+        p3 = t0 + t2;
+        long long p4 = t1 + t3;
+        p1 = t0 + t3;
+        p2 = t1 + t2;
+        const long long p5 = ( p3 + p4 ) * Fixed( 1.175875602f );
         t0 = t0 * Fixed( 0.298631336f );
         t1 = t1 * Fixed( 2.053119869f );
         t2 = t2 * Fixed( 3.072711026f );
@@ -84,12 +85,15 @@ namespace
         t[0] = t0 + p1 + p3;
     }
 
+    int Narrow( long long x ) { return x < -0x40000000ll ? -0x40000000 : ( x > 0x3fffffffll ? 0x3fffffff : static_cast< int >( x ) ); }
+
     void InverseDctBlock( const int16_t coefficients[64], uint8_t* out, int stride )
     {
         int mid[64];
         for ( int c = 0; c < 8; ++c ) // columns, two extra bits of precision kept
         {
-            int s[8], x[4], t[4];
+            int s[8];
+            long long x[4], t[4];
             bool acZero = true;
             for ( int r = 0; r < 8; ++r )
             {
@@ -104,16 +108,16 @@ namespace
             InverseDct1D( s, x, t );
             for ( int k = 0; k < 4; ++k )
             {
-                mid[8 * k + c]         = ( x[k] + 512 + t[3 - k] ) >> 10;
-                mid[8 * ( 7 - k ) + c] = ( x[k] + 512 - t[3 - k] ) >> 10;
+                mid[8 * k + c]         = Narrow( ( x[k] + 512 + t[3 - k] ) >> 10 );
+                mid[8 * ( 7 - k ) + c] = Narrow( ( x[k] + 512 - t[3 - k] ) >> 10 );
             }
         }
         for ( int r = 0; r < 8; ++r ) // rows: 12 bits of the constants, 2 kept above, 3 of the two sqrt(8) scalings
         {
-            int x[4], t[4];
+            long long x[4], t[4];
             InverseDct1D( mid + 8 * r, x, t );
-            uint8_t* o     = out + static_cast< size_t >( r ) * stride;
-            const int bias = 65536 + ( 128 << 17 ); // rounding, and the level shift back to 0..255
+            uint8_t* o           = out + static_cast< size_t >( r ) * stride;
+            const long long bias = 65536 + ( 128 << 17 ); // rounding, and the level shift back to 0..255
             for ( int k = 0; k < 4; ++k )
             {
                 o[k]     = Clamp8( ( x[k] + bias + t[3 - k] ) >> 17 );
