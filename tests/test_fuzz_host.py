@@ -1,0 +1,118 @@
+"""The host library's file readers (images, scene JSON, OBJ / MTL) on damaged input, under AddressSanitizer and
+UndefinedBehaviorSanitizer: a reader may refuse a file, it may not read or write out of bounds.  Host code only."""
+import glob
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from pathtracer_amd import host
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+OBJ = """mtllib model.mtl
+v -1 0 -1
+v 1 0 -1
+v 1 0 1
+v -1 0 1
+v 0 1.5 0
+vt 0 0
+vt 1 0
+vt 1 1
+vt 0 1
+vn 0 1 0
+usemtl floor
+f 1/1/1 2/2/1 3/3/1 4/4/1
+usemtl lamp
+f -1 1 2
+f 5//1 2//1 3//1
+g side
+f 5/1 3/2 4/3
+"""
+MTL = """newmtl floor
+Kd 0.7 0.6 0.5
+Ks 0 0 0
+Ns 10
+map_Kd checker.tga
+newmtl lamp
+Kd 0.8 0.8 0.8
+Ke 5 4 3
+"""
+SCENE = """{
+ "OutputImageData": { "resolution": [ 32, 24 ], "filename": "out.png" },
+ "Camera": { "position": [ 0, 1, 4 ], "rotation": [ -10, 0, 0 ], "vfov": 45, "aspectRatio": 1.333, "exposure": 1.0, "gamma": 2.2 },
+ "BVH": { "splitMethod": "SAH" }, "MaxDepth": 3, "SamplesPerPixel": [ 2, 4 ], "SamplesPerAreaLight": 2,
+ "BackgroundColor": { "color": [ 0.1, 0.2, 0.3 ] },
+ "PointLight": { "position": [ 0, 3, 0 ], "Lemit": [ 5, 5, 5 ] },
+ "DirectionalLight": { "direction": [ 0, -1, -1 ], "Lemit": [ 1, 1, 1 ] },
+ "Texture": { "name": "checker", "filename": "models/checker.tga" },
+ "Material": { "name": "grey", "albedo": [ 0.5, 0.5, 0.5 ], "albedoTexture": "checker" },
+ "Model": { "name": "m", "filename": "models/model.obj" },
+ "ModelInstance": { "model": "m", "transform": { "position": [ 0, 0, 0 ], "rotation": [ 0, 30, 0 ], "scale": [ 1, 1, 1 ] } },
+ "ModelInstance": { "model": "m", "material": "grey", "transform": { "position": [ 2, 0, -1 ] } },
+ "Sphere": { "material": "grey", "position": [ -2, 1, 0 ], "radius": 0.7 }
+}
+"""
+
+
+@pytest.fixture(scope="module")
+def fuzzer(tmp_path_factory):
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    out = str(tmp_path_factory.mktemp("fuzz") / "fuzz_host")
+    sources = [f for f in glob.glob(os.path.join(ROOT, "pathtracer_amd", "host", "*.cpp")) if os.path.basename(f) not in ("main.cpp", "c_api.cpp")]
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-pthread", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "pathtracer_amd", "host"),
+           os.path.join(ROOT, "tests", "fuzz", "fuzz_host.cpp")] + sources + ["-o", out]
+    subprocess.run(cmd, check=True, capture_output=True, text=True)
+    return out
+
+
+def run(fuzzer, *args):
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0")
+    env.pop("LD_PRELOAD", None)   # the sanitizer runtime has to come first in the library list
+    p = subprocess.run([fuzzer, *args], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    accepted, refused = int(p.stdout.split()[0]), int(p.stdout.split()[2])
+    assert accepted > 0 and refused > 0, p.stdout
+    return accepted, refused
+
+
+def test_image_readers_survive_damaged_files(fuzzer, tmp_path):
+    rng = np.random.default_rng(1)
+    picture = (rng.integers(0, 4, (40, 50, 3)) * 80).astype(np.float32) / 255
+    files = []
+    for ext in ("tga", "bmp", "ppm"):
+        f = str(tmp_path / f"picture.{ext}")
+        host.write_image(f, picture)
+        files.append(f)
+    try:
+        import PIL.Image
+        img = PIL.Image.fromarray((picture * 255).astype(np.uint8))
+        img.save(str(tmp_path / "rle.tga"), compression="tga_rle")
+        img.save(str(tmp_path / "picture.jpg"), quality=70)
+        img.save(str(tmp_path / "restart.jpg"), quality=70, subsampling=0, restart_marker_blocks=2)
+        files += [str(tmp_path / "rle.tga"), str(tmp_path / "picture.jpg"), str(tmp_path / "restart.jpg")]
+    except ImportError:
+        pass
+    for f in files:
+        run(fuzzer, "image", f, "250")
+
+
+def test_scene_and_model_readers_survive_damaged_files(fuzzer, tmp_path):
+    os.makedirs(tmp_path / "scenes")
+    os.makedirs(tmp_path / "models")
+    (tmp_path / "scenes" / "base.json").write_text(SCENE)
+    (tmp_path / "models" / "base.obj").write_text(OBJ)
+    (tmp_path / "models" / "base.mtl").write_text(MTL)
+    checker = np.indices((8, 8)).sum(axis=0) % 2
+    host.write_image(str(tmp_path / "models" / "checker.tga"), np.repeat(checker[..., None], 3, axis=2).astype(np.float32))
+    # the undamaged files load
+    shutil.copy(tmp_path / "models" / "base.obj", tmp_path / "models" / "model.obj")
+    shutil.copy(tmp_path / "models" / "base.mtl", tmp_path / "models" / "model.mtl")
+    with host.HostScene.from_file(str(tmp_path / "scenes" / "base.json"), str(tmp_path) + "/") as hs:
+        scene = hs.to_data()
+        assert len(scene.prims) == 2 * 5 + 1 and len(scene.textures) >= 1   # the JSON texture and the MTL map_Kd
+    run(fuzzer, "scene", str(tmp_path), "400")
