@@ -72,7 +72,7 @@ int pth_sphere_world_to_local( const float position[3], const float rotation[3],
 int pth_write_image( const char* filename, const float* rgb, int32_t width, int32_t height );
 
 /* Texture::Load's decode (src/resource/texture.cpp:19-33: stbi_load with four channels, rows flipped when asked):
- * RGBA8, row 0 first.  Call with rgba = NULL to get the size.  TGA, BMP, PPM / PGM. */
+ * RGBA8, row 0 first.  Call with rgba = NULL to get the size.  TGA, PNG, baseline JPEG, BMP, PPM / PGM. */
 int pth_read_image( const char* filename, int32_t flip_vertically, int32_t* width, int32_t* height, uint8_t* rgba, uint64_t capacity );
 
 const char* pth_last_error( void );

@@ -254,8 +254,9 @@ bool ReadImageRGBA8( const std::string& filename, bool flipVertically, ImageRGBA
     if ( f.size() > 2 && f[0] == 'P' && ( f[1] == '5' || f[1] == '6' ) ) ok = ReadPnm( f, out, error );
     else if ( f.size() > 2 && f[0] == 'B' && f[1] == 'M' ) ok = ReadBmp( f, out, error );
     else if ( f.size() > 2 && f[0] == 0xFF && f[1] == 0xD8 ) ok = ReadJpegRGBA8( filename, out, error );
+    else if ( f.size() > 4 && f[0] == 0x89 && f[1] == 'P' && f[2] == 'N' && f[3] == 'G' ) ok = ReadPngRGBA8( f, out, error );
     else if ( ext == "tga" ) ok = ReadTga( f, out, error );
-    else error = "image format of '" + filename + "' is not decoded by this host (TGA, baseline JPEG, BMP, PPM only)";
+    else error = "image format of '" + filename + "' is not decoded by this host (TGA, PNG, baseline JPEG, BMP, PPM only)";
     if ( !ok )
     {
         error = "Failed to load image '" + filename + "': " + error;

@@ -17,12 +17,15 @@ struct ImageRGBA8
 // Reads TGA (types 2, 3, 10, 11; 8/24/32 bit), binary PPM/PGM (P5, P6) and uncompressed 24/32-bit BMP into
 // RGBA8 with the top row first, then flips the rows if `flipVertically` - the contract of
 // stbi_load(..., 4) with stbi_set_flip_vertically_on_load as used by Texture::Load
-// (src/resource/texture.cpp:19-33).  Also baseline JPEG (jpeg_decoder.cpp); progressive JPEG and PNG input are
-// not decoded here.
+// (src/resource/texture.cpp:19-33).  Also PNG (png_decoder.cpp) and baseline JPEG (jpeg_decoder.cpp); progressive
+// JPEG input is not decoded here.
 bool ReadImageRGBA8( const std::string& filename, bool flipVertically, ImageRGBA8& out, std::string& error );
 
 // Baseline JPEG with the arithmetic of the reference's decoder (jpeg_decoder.cpp); rows as stored, top row first.
 bool ReadJpegRGBA8( const std::string& filename, ImageRGBA8& out, std::string& error );
+
+// PNG of any colour type, bit depth and interlacing, converted to 8-bit RGBA the way the reference's decoder does.
+bool ReadPngRGBA8( const std::vector< uint8_t >& file, ImageRGBA8& out, std::string& error );
 
 // The reference's quantiser (src/image.cpp:57-68): 255 * clamp(c, 0, 1) truncated to uint8.
 std::vector< uint8_t > QuantizeRGB8( const float* rgb, int width, int height );

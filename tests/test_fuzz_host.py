@@ -84,7 +84,7 @@ def test_image_readers_survive_damaged_files(fuzzer, tmp_path):
     rng = np.random.default_rng(1)
     picture = (rng.integers(0, 4, (40, 50, 3)) * 80).astype(np.float32) / 255
     files = []
-    for ext in ("tga", "bmp", "ppm"):
+    for ext in ("tga", "bmp", "ppm", "png"):
         f = str(tmp_path / f"picture.{ext}")
         host.write_image(f, picture)
         files.append(f)
@@ -94,7 +94,9 @@ def test_image_readers_survive_damaged_files(fuzzer, tmp_path):
         img.save(str(tmp_path / "rle.tga"), compression="tga_rle")
         img.save(str(tmp_path / "picture.jpg"), quality=70)
         img.save(str(tmp_path / "restart.jpg"), quality=70, subsampling=0, restart_marker_blocks=2)
-        files += [str(tmp_path / "rle.tga"), str(tmp_path / "picture.jpg"), str(tmp_path / "restart.jpg")]
+        img.save(str(tmp_path / "deflated.png"), optimize=True)
+        img.convert("P").save(str(tmp_path / "palette.png"))
+        files += [str(tmp_path / n) for n in ("rle.tga", "picture.jpg", "restart.jpg", "deflated.png", "palette.png")]
     except ImportError:
         pass
     for f in files:

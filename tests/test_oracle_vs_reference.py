@@ -281,3 +281,48 @@ def test_cube_map_faces_from_the_reference_files(tmp_path):
     for k, name in enumerate(("right", "left", "top", "bottom", "back", "front")):
         want = ref.load_texture(res + f"images/water/{name}.jpg", flip=False).astype(np.float32) / np.float32(255)
         assert np.array_equal(faces[k], want), name
+
+
+def test_png_decoding_equals_the_reference_texture_load(tmp_path):
+    """PNG through the host library and through the reference's Texture::Load (stb_image): every colour type at
+    every bit depth it allows, interlaced and not, each row filter, colour keys and palette transparency,
+    several IDAT chunks, odd sizes down to 1 x 1 (tests/png_writer.py), and files written by Pillow with
+    different deflate settings (stored, fixed and dynamic Huffman blocks) - equal bytes."""
+    from png_writer import write_png, CHANNELS
+    rng = np.random.default_rng(4)
+    files = []
+
+    def new():
+        files.append(str(tmp_path / f"{len(files)}.png"))
+        return files[-1]
+
+    for (w, h) in ((37, 29), (8, 8), (1, 1), (5, 1), (1, 7), (9, 16)):
+        for colour_type, depths in ((0, (1, 2, 4, 8, 16)), (2, (8, 16)), (3, (1, 2, 4, 8)), (4, (8, 16)), (6, (8, 16))):
+            for depth in depths:
+                top = min(1 << depth, 1 << 16)
+                samples = rng.integers(0, top, (h, w, CHANNELS[colour_type]))
+                samples[: h // 2] = (np.arange(w)[None, :, None] * 3 + np.arange(h // 2)[:, None, None]) % top   # smooth half: filters matter
+                kw = {}
+                if colour_type == 3:
+                    kw["palette"] = rng.integers(0, 256, (top, 3))
+                for interlace in (False, True):
+                    write_png(new(), samples, colour_type, depth, interlace=interlace, idat_split=(0 if interlace else 40), **kw)
+                    if colour_type == 3:
+                        write_png(new(), samples, colour_type, depth, interlace=interlace, trns=rng.integers(0, 256, top // 2 + 1).astype(np.uint8), **kw)
+                    elif colour_type in (0, 2):
+                        key = samples[h - 1, w - 1]
+                        write_png(new(), samples, colour_type, depth, interlace=interlace, trns=b"".join(int(v).to_bytes(2, "big") for v in key))
+                if (w, h) == (37, 29):
+                    for f in range(5):
+                        write_png(new(), samples, colour_type, depth, row_filter=f, **kw)
+    PIL = pytest.importorskip("PIL.Image")
+    picture = rng.integers(0, 256, (40, 56, 4)).astype(np.uint8)
+    picture[:20] = (np.arange(56)[None, :, None] * 4) % 256
+    for mode in ("RGBA", "RGB", "L", "LA", "P", "1"):
+        for kw in ({}, {"optimize": True}, {"compress_level": 0}, {"compress_level": 1}, {"compress_level": 9}):
+            PIL.fromarray(picture).convert(mode).save(new(), **kw)
+    assert len(files) > 400
+    for f in files:
+        for flip in (True, False):
+            mine, theirs = host.read_image(f, flip), ref.load_texture(f, flip=flip)
+            assert mine.shape == theirs.shape and np.array_equal(mine, theirs), (f, flip)
