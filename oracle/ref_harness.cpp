@@ -18,6 +18,7 @@
 // Consequently the skybox lookup (skybox.cpp:84-118), the scene parser and the Assimp import are not
 // covered by this harness.
 #include "bvh.hpp"
+#include "image.hpp"
 #include "anti_aliasing.hpp"
 #include "intersection_tests.hpp"
 #include "lights.hpp"
@@ -636,6 +637,20 @@ int ref_render( RefScene* r, const float cameraRotation[3], int spp, uint64_t se
 #endif
     std::memcpy( rgbTonemapped, tracer.renderedImage.GetPixels(), static_cast< size_t >( r->width ) * r->height * 12 );
     return 0;
+}
+
+// The reference's Image::Save (src/image.cpp:43-100) on a caller's picture: W * H * 3 floats, row-major.
+int ref_save_image( const char* filename, const float* rgb, int width, int height )
+{
+    if ( !filename || !rgb || width <= 0 || height <= 0 ) return Fail( "ref_save_image: bad argument" );
+    PT::Image image( width, height );
+    for ( int r = 0; r < height; ++r )
+        for ( int c = 0; c < width; ++c )
+        {
+            const float* p = rgb + 3 * ( static_cast< size_t >( r ) * width + c );
+            image.SetPixel( r, c, glm::vec3( p[0], p[1], p[2] ) );
+        }
+    return image.Save( filename ) ? 0 : Fail( "Image::Save failed" );
 }
 
 } // extern "C"

@@ -1,6 +1,7 @@
 #include "image_io.hpp"
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 
@@ -198,6 +199,165 @@ namespace
         PutBE32( file, Crc32( body.data(), body.size() ) );
     }
 
+    // ---- PNG as the reference writes it (stb_image_write 1.14 behind Image::Save, src/image.cpp:43-100), so that a
+    // rendered picture is the same file byte for byte: per row the filter whose output has the smallest sum of
+    // absolute values (first wins a tie; on the first row "up" degenerates to "none" and "average" / "Paeth" to
+    // their left-only forms, the filter byte still says what was asked for), then one fixed-Huffman deflate block
+    // whose matches come from 16,384 hash buckets of at most 16 positions (the older 8 dropped when full), the
+    // longest match winning and the latest of equal ones, deferred by one byte when the next position has a longer.
+
+    int PaethPredictor( int a, int b, int c )
+    {
+        const int p = a + b - c, pa = std::abs( p - a ), pb = std::abs( p - b ), pc = std::abs( p - c );
+        return ( pa <= pb && pa <= pc ) ? a : ( pb <= pc ? b : c );
+    }
+
+    void FilterRow( const uint8_t* row, const uint8_t* above, int bytes, int filter, int8_t* out )
+    {
+        // operation: 0 none, 1 sub, 2 up, 3 average, 4 Paeth; 5 / 6 = average / Paeth of a first row
+        const int op = above ? filter : ( filter == 2 ? 0 : ( filter == 3 ? 5 : ( filter == 4 ? 6 : filter ) ) );
+        for ( int i = 0; i < bytes; ++i )
+        {
+            const int left = i >= 3 ? row[i - 3] : 0, up = above ? above[i] : 0, upLeft = ( above && i >= 3 ) ? above[i - 3] : 0;
+            int predicted = 0;
+            switch ( op )
+            {
+                case 1: predicted = left; break;
+                case 2: predicted = up; break;
+                case 3: predicted = ( left + up ) >> 1; break;
+                case 4: predicted = PaethPredictor( left, up, upLeft ); break;
+                case 5: predicted = left >> 1; break;
+                case 6: predicted = left; break;
+                default: break;
+            }
+            out[i] = static_cast< int8_t >( static_cast< uint8_t >( row[i] - predicted ) );
+        }
+    }
+
+    class FixedDeflater
+    {
+    public:
+        std::vector< uint8_t > out;
+
+        void Compress( const uint8_t* data, int size, int quality )
+        {
+            static const uint16_t lengthBase[30] = { 3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258, 259 };
+            static const uint8_t lengthExtra[29] = { 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0 };
+            static const uint16_t distanceBase[31] = { 1,   2,   3,   4,   5,   7,    9,    13,   17,   25,   33,   49,   65,    97,    129,  193,
+                                                       257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577, 32768 };
+            static const uint8_t distanceExtra[30] = { 0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13 };
+            constexpr int kBuckets = 16384;
+            std::vector< std::vector< int > > buckets( kBuckets );
+            out = { 0x78, 0x5e };
+            Add( 1, 1 ); // last block
+            Add( 1, 2 ); // fixed Huffman codes
+            int i = 0;
+            while ( i < size - 3 )
+            {
+                int best = 3, bestAt = -1;
+                std::vector< int >& bucket = buckets[Hash( data + i ) & ( kBuckets - 1 )];
+                for ( int at : bucket )
+                    if ( at > i - 32768 )
+                    {
+                        const int n = MatchLength( data + at, data + i, size - i );
+                        if ( n >= best )
+                        {
+                            best   = n;
+                            bestAt = at;
+                        }
+                    }
+                if ( static_cast< int >( bucket.size() ) == 2 * quality ) bucket.erase( bucket.begin(), bucket.begin() + quality );
+                bucket.push_back( i );
+                if ( bestAt >= 0 )
+                    for ( int at : buckets[Hash( data + i + 1 ) & ( kBuckets - 1 )] )
+                        if ( at > i - 32767 && MatchLength( data + at, data + i + 1, size - i - 1 ) > best )
+                        {
+                            bestAt = -1; // the next byte starts a longer match: this one goes out as a literal
+                            break;
+                        }
+                if ( bestAt >= 0 )
+                {
+                    const int distance = i - bestAt;
+                    int j = 0;
+                    while ( best > lengthBase[j + 1] - 1 ) ++j;
+                    Symbol( j + 257 );
+                    if ( lengthExtra[j] ) Add( static_cast< uint32_t >( best - lengthBase[j] ), lengthExtra[j] );
+                    j = 0;
+                    while ( distance > distanceBase[j + 1] - 1 ) ++j;
+                    Add( Reverse( j, 5 ), 5 );
+                    if ( distanceExtra[j] ) Add( static_cast< uint32_t >( distance - distanceBase[j] ), distanceExtra[j] );
+                    i += best;
+                }
+                else
+                    Symbol( data[i++] );
+            }
+            for ( ; i < size; ++i ) Symbol( data[i] );
+            Symbol( 256 );
+            while ( m_count ) Add( 0, 1 );
+            uint32_t a = 1, b = 0;
+            for ( int k = 0; k < size; ++k )
+            {
+                a = ( a + data[k] ) % 65521;
+                b = ( b + a ) % 65521;
+            }
+            for ( uint32_t v : { b >> 8, b, a >> 8, a } ) out.push_back( static_cast< uint8_t >( v ) );
+        }
+
+    private:
+        uint32_t m_bits = 0;
+        int m_count     = 0;
+
+        void Add( uint32_t code, int bits )
+        {
+            m_bits |= code << m_count;
+            m_count += bits;
+            while ( m_count >= 8 )
+            {
+                out.push_back( static_cast< uint8_t >( m_bits ) );
+                m_bits >>= 8;
+                m_count -= 8;
+            }
+        }
+
+        static uint32_t Reverse( int code, int bits )
+        {
+            uint32_t r = 0;
+            while ( bits-- )
+            {
+                r = r << 1 | ( code & 1 );
+                code >>= 1;
+            }
+            return r;
+        }
+
+        void Symbol( int n ) // literal / length alphabet of the fixed code
+        {
+            if ( n <= 143 ) Add( Reverse( 0x30 + n, 8 ), 8 );
+            else if ( n <= 255 ) Add( Reverse( 0x190 + n - 144, 9 ), 9 );
+            else if ( n <= 279 ) Add( Reverse( n - 256, 7 ), 7 );
+            else Add( Reverse( 0xc0 + n - 280, 8 ), 8 );
+        }
+
+        static int MatchLength( const uint8_t* a, const uint8_t* b, int limit )
+        {
+            int n = 0;
+            while ( n < limit && n < 258 && a[n] == b[n] ) ++n;
+            return n;
+        }
+
+        static uint32_t Hash( const uint8_t* d )
+        {
+            uint32_t h = d[0] + ( d[1] << 8 ) + ( d[2] << 16 );
+            h ^= h << 3;
+            h += h >> 5;
+            h ^= h << 4;
+            h += h >> 17;
+            h ^= h << 25;
+            h += h >> 6;
+            return h;
+        }
+    };
+
     std::vector< uint8_t > EncodePng( const uint8_t* rgb, int w, int h )
     {
         std::vector< uint8_t > file = { 0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a };
@@ -207,34 +367,33 @@ namespace
         ihdr.insert( ihdr.end(), { 8, 2, 0, 0, 0 } );
         PngChunk( file, "IHDR", ihdr );
 
-        std::vector< uint8_t > raw;
-        raw.reserve( static_cast< size_t >( h ) * ( 3 * w + 1 ) );
+        const int bytes = 3 * w;
+        std::vector< uint8_t > raw( static_cast< size_t >( h ) * ( bytes + 1 ) );
+        std::vector< int8_t > line( bytes ), bestLine( bytes );
         for ( int r = 0; r < h; ++r )
         {
-            raw.push_back( 0 ); // filter: none
-            raw.insert( raw.end(), rgb + static_cast< size_t >( r ) * 3 * w, rgb + static_cast< size_t >( r + 1 ) * 3 * w );
-        }
-        std::vector< uint8_t > z = { 0x78, 0x01 };
-        uint32_t a = 1, b = 0;
-        size_t pos = 0;
-        do
-        {
-            size_t n = std::min< size_t >( 65535, raw.size() - pos );
-            z.push_back( pos + n == raw.size() ? 1 : 0 );
-            z.push_back( n & 0xff );
-            z.push_back( n >> 8 );
-            z.push_back( ~n & 0xff );
-            z.push_back( ( ~n >> 8 ) & 0xff );
-            z.insert( z.end(), raw.begin() + pos, raw.begin() + pos + n );
-            for ( size_t i = 0; i < n; ++i )
+            const uint8_t* row   = rgb + static_cast< size_t >( r ) * bytes;
+            const uint8_t* above = r ? row - bytes : nullptr;
+            int best = 0, bestSum = 0x7fffffff;
+            for ( int filter = 0; filter < 5; ++filter )
             {
-                a = ( a + raw[pos + i] ) % 65521;
-                b = ( b + a ) % 65521;
+                FilterRow( row, above, bytes, filter, line.data() );
+                int sum = 0;
+                for ( int i = 0; i < bytes; ++i ) sum += std::abs( static_cast< int >( line[i] ) );
+                if ( sum < bestSum )
+                {
+                    bestSum = sum;
+                    best    = filter;
+                    bestLine.swap( line );
+                }
             }
-            pos += n;
-        } while ( pos < raw.size() );
-        PutBE32( z, ( b << 16 ) | a );
-        PngChunk( file, "IDAT", z );
+            uint8_t* o = &raw[static_cast< size_t >( r ) * ( bytes + 1 )];
+            o[0]       = static_cast< uint8_t >( best );
+            std::memcpy( o + 1, bestLine.data(), bytes );
+        }
+        FixedDeflater deflater;
+        deflater.Compress( raw.data(), static_cast< int >( raw.size() ), 8 );
+        PngChunk( file, "IDAT", deflater.out );
         PngChunk( file, "IEND", {} );
         return file;
     }
@@ -291,6 +450,8 @@ bool WriteImageRGB8( const std::string& filename, const uint8_t* rgb, int width,
     std::vector< uint8_t > file;
     if ( ext == "png" )
         file = EncodePng( rgb, width, height );
+    else if ( ext == "jpg" || ext == "jpeg" )
+        file = EncodeJpegRGB8( rgb, width, height );
     else if ( ext == "ppm" )
     {
         std::string header = "P6\n" + std::to_string( width ) + " " + std::to_string( height ) + "\n255\n";
@@ -299,19 +460,66 @@ bool WriteImageRGB8( const std::string& filename, const uint8_t* rgb, int width,
     }
     else if ( ext == "tga" )
     {
+        // Run-length encoded true colour (type 10), bottom row first, as the reference's writer emits it
+        // (stb_image_write 1.14 behind Image::Save, src/image.cpp:43-100).  Packets never cross a row.  A run
+        // packet repeats one pixel up to 128 times.  A raw packet starts when the first two pixels differ and is
+        // extended pixel by pixel while pixel k differs from pixel k - 2 (sic: two back, not one); when they are
+        // equal the packet ends one pixel early, so that pixel k - 1 can open the next packet.
         file.assign( 18, 0 );
-        file[2]  = 2;
+        file[2]  = 10;
         file[12] = width & 0xff;
-        file[13] = width >> 8;
+        file[13] = ( width >> 8 ) & 0xff;
         file[14] = height & 0xff;
-        file[15] = height >> 8;
+        file[15] = ( height >> 8 ) & 0xff;
         file[16] = 24;
-        file[17] = 0x20;
-        for ( size_t i = 0; i < static_cast< size_t >( width ) * height; ++i )
-            file.insert( file.end(), { rgb[3 * i + 2], rgb[3 * i + 1], rgb[3 * i] } );
+        auto same = [&]( const uint8_t* a, const uint8_t* b ) { return a[0] == b[0] && a[1] == b[1] && a[2] == b[2]; };
+        auto put  = [&]( const uint8_t* p ) { file.insert( file.end(), { p[2], p[1], p[0] } ); };
+        for ( int r = height - 1; r >= 0; --r )
+        {
+            const uint8_t* row = rgb + 3 * static_cast< size_t >( r ) * width;
+            int length = 1;
+            for ( int i = 0; i < width; i += length )
+            {
+                const uint8_t* begin = row + 3 * i;
+                bool run = false;
+                length   = 1;
+                if ( i < width - 1 )
+                {
+                    length = 2;
+                    run    = same( begin, begin + 3 );
+                    if ( !run )
+                    {
+                        const uint8_t* twoBack = begin;
+                        for ( int k = i + 2; k < width && length < 128; ++k )
+                        {
+                            if ( same( twoBack, row + 3 * k ) )
+                            {
+                                --length;
+                                break;
+                            }
+                            twoBack += 3;
+                            ++length;
+                        }
+                    }
+                    else
+                        for ( int k = i + 2; k < width && length < 128 && same( begin, row + 3 * k ); ++k ) ++length;
+                }
+                if ( run )
+                {
+                    file.push_back( static_cast< uint8_t >( length - 129 ) );
+                    put( begin );
+                }
+                else
+                {
+                    file.push_back( static_cast< uint8_t >( length - 1 ) );
+                    for ( int k = 0; k < length; ++k ) put( begin + 3 * k );
+                }
+            }
+        }
     }
     else if ( ext == "bmp" )
     {
+        // 24 bit, bottom row first, rows padded to four bytes, the size-of-image and resolution fields left zero
         const size_t stride = ( static_cast< size_t >( width ) * 3 + 3 ) & ~size_t( 3 );
         const uint32_t size = static_cast< uint32_t >( 54 + stride * height );
         file.assign( 54, 0 );
@@ -325,7 +533,6 @@ bool WriteImageRGB8( const std::string& filename, const uint8_t* rgb, int width,
         put32( 22, height );
         file[26] = 1;
         file[28] = 24;
-        put32( 34, static_cast< uint32_t >( stride * height ) );
         for ( int r = height - 1; r >= 0; --r )
         {
             size_t start = file.size();

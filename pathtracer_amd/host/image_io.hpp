@@ -30,8 +30,11 @@ bool ReadPngRGBA8( const std::vector< uint8_t >& file, ImageRGBA8& out, std::str
 // The reference's quantiser (src/image.cpp:57-68): 255 * clamp(c, 0, 1) truncated to uint8.
 std::vector< uint8_t > QuantizeRGB8( const float* rgb, int width, int height );
 
-// Writes 8-bit RGB as .png (stored deflate blocks), .tga, .bmp or .ppm by extension, like Image::Save
-// (src/image.cpp:43-100; .jpg is not written here).
+// Writes 8-bit RGB as .png, .tga, .bmp, .jpg / .jpeg (or, beyond the reference, .ppm) by extension.  The first four
+// come out byte for byte as Image::Save writes them (src/image.cpp:43-100, stb_image_write 1.14): PNG with its
+// per-row filter choice and fixed-Huffman deflate, run-length TGA, 24-bit BMP, quality-95 4:4:4 baseline JPEG.
+// Width and height must be at most 65535 for .tga and .jpg.
+std::vector< uint8_t > EncodeJpegRGB8( const uint8_t* rgb, int width, int height );
 bool WriteImageRGB8( const std::string& filename, const uint8_t* rgb, int width, int height, std::string& error );
 
 } // namespace pth

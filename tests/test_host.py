@@ -158,7 +158,7 @@ def test_procedural_scenes_have_the_requested_size():
 
 
 def test_image_writer_quantises_like_the_reference(tmp_path):
-    """255 * clamp(c, 0, 1) truncated (src/image.cpp:57-68); PNG/TGA/BMP/PPM writers produce readable files."""
+    """255 * clamp(c, 0, 1) truncated (src/image.cpp:57-68); PNG/TGA/BMP/JPEG/PPM writers produce files the readers read back."""
     rgb = np.array([[[0.0, 0.5, 1.0], [1.5, -0.2, 0.999]], [[0.25, 0.75, 0.1], [0.2, 0.3, 0.4]]], np.float32)
     want = np.array([[[0, 127, 255], [255, 0, 254]], [[63, 191, 25], [51, 76, 102]]], np.uint8)
     ppm = tmp_path / "o.ppm"
@@ -168,13 +168,15 @@ def test_image_writer_quantises_like_the_reference(tmp_path):
     for ext in ("png", "tga", "bmp"):
         f = tmp_path / f"o.{ext}"
         host.write_image(str(f), rgb)
-        assert f.stat().st_size > 12
+        assert np.array_equal(host.read_image(str(f), False)[..., :3], want), ext
     png = (tmp_path / "o.png").read_bytes()
     assert png[:8] == b"\x89PNG\r\n\x1a\n"
     import zlib
     idat = png[png.index(b"IDAT") + 4: png.index(b"IEND") - 8]
-    raw = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(2, 7)
-    assert np.array_equal(raw[:, 1:].reshape(2, 2, 3), want)
+    assert len(zlib.decompress(idat)) == 2 * 7                     # a valid zlib stream of two filtered rows
+    jpg = tmp_path / "o.jpg"
+    host.write_image(str(jpg), rgb)
+    assert jpg.read_bytes()[:2] == b"\xff\xd8" and host.read_image(str(jpg), False).shape == (2, 2, 4)
     with pytest.raises(host.HostError):
         host.write_image(str(tmp_path / "o.xyz"), rgb)
 

@@ -326,3 +326,50 @@ def test_png_decoding_equals_the_reference_texture_load(tmp_path):
         for flip in (True, False):
             mine, theirs = host.read_image(f, flip), ref.load_texture(f, flip=flip)
             assert mine.shape == theirs.shape and np.array_equal(mine, theirs), (f, flip)
+
+
+def writer_pictures():
+    """Float pictures for the image writers: noise beyond [0, 1], gradients, long runs and runs of exactly three
+    (run-length packets, deflate matches), flat black and white, a smooth shaded picture of rendered size, and
+    sizes that leave partial 8 x 8 blocks, one-pixel rows and rows longer than a 128-pixel packet."""
+    rng = np.random.default_rng(0)
+    pics = []
+    for (w, h) in ((53, 37), (1, 1), (2, 1), (1, 2), (3, 3), (130, 5), (257, 4), (300, 2), (8, 8), (16, 16), (64, 48)):
+        p = rng.uniform(-0.2, 1.2, (h, w, 3)).astype(np.float32)
+        pics.append(p)
+        q = p.copy()
+        q[: h // 2 + 1] = np.linspace(0, 1, w, dtype=np.float32)[None, :, None]
+        pics.append(q)
+        r = np.round(rng.uniform(0, 1, (h, w, 1)) * 3) / 3 * np.ones(3)
+        r[:, : w // 2] = 0.5
+        pics.append(r.astype(np.float32))
+        pics.append(np.repeat(rng.integers(0, 2, (h, (w + 2) // 3, 3)), 3, axis=1)[:, :w].astype(np.float32))
+    pics.append(np.zeros((19, 21, 3), np.float32))
+    pics.append(np.ones((19, 21, 3), np.float32))
+    y, x = np.mgrid[0:360, 0:640].astype(np.float32)
+    shaded = np.stack([0.5 + 0.5 * np.sin(x / 47 + y / 91), (x / 640) * (y / 360), 0.3 + 0.2 * np.cos(y / 13)], axis=-1)
+    shaded += rng.normal(0, 0.02, shaded.shape)            # the grain of a path-traced picture
+    shaded[100:200, 200:400] = (0.9, 0.1, 0.1)             # a flat surface with hard edges
+    pics.append(shaded.astype(np.float32))
+    return pics
+
+
+@pytest.mark.parametrize("ext", ["png", "tga", "bmp", "jpg", "jpeg"])
+def test_image_writers_equal_the_reference_image_save(ext, tmp_path):
+    """Every file format Image::Save writes (src/image.cpp:43-100, stb_image_write 1.14 underneath): the host
+    library's file equals the reference's byte for byte - PNG row filter choice and deflate matches, TGA packets,
+    BMP header fields, JPEG tables, coefficients and entropy coding - and reads back to the quantised pixels
+    (exactly, but for JPEG)."""
+    theirs, mine = str(tmp_path / f"theirs.{ext}"), str(tmp_path / f"mine.{ext}")
+    for n, pic in enumerate(writer_pictures()):
+        ref.save_image(theirs, pic)
+        host.write_image(mine, pic)
+        a, b = open(theirs, "rb").read(), open(mine, "rb").read()
+        assert a == b, (ext, n, pic.shape, len(a), len(b), next((i for i in range(min(len(a), len(b))) if a[i] != b[i]), -1))
+        back = host.read_image(mine, False)[..., :3]
+        quantised = (255.0 * np.minimum(np.maximum(pic, np.float32(0)), np.float32(1))).astype(np.uint8)
+        if ext in ("jpg", "jpeg"):
+            assert back.shape == quantised.shape
+            assert np.abs(back.astype(int) - quantised).mean() < 6
+        else:
+            assert np.array_equal(back, quantised), (ext, n)
