@@ -17,11 +17,11 @@ struct ImageRGBA8
 // Reads TGA (types 2, 3, 10, 11; 8/24/32 bit), binary PPM/PGM (P5, P6) and uncompressed 24/32-bit BMP into
 // RGBA8 with the top row first, then flips the rows if `flipVertically` - the contract of
 // stbi_load(..., 4) with stbi_set_flip_vertically_on_load as used by Texture::Load
-// (src/resource/texture.cpp:19-33).  Also PNG (png_decoder.cpp) and baseline JPEG (jpeg_decoder.cpp); progressive
-// JPEG input is not decoded here.
+// (src/resource/texture.cpp:19-33).  Also PNG (png_decoder.cpp) and baseline or progressive JPEG
+// (jpeg_decoder.cpp).
 bool ReadImageRGBA8( const std::string& filename, bool flipVertically, ImageRGBA8& out, std::string& error );
 
-// Baseline JPEG with the arithmetic of the reference's decoder (jpeg_decoder.cpp); rows as stored, top row first.
+// Baseline or progressive JPEG with the arithmetic of the reference's decoder (jpeg_decoder.cpp); rows as stored, top row first.
 bool ReadJpegRGBA8( const std::string& filename, ImageRGBA8& out, std::string& error );
 
 // PNG of any colour type, bit depth and interlacing, converted to 8-bit RGBA the way the reference's decoder does.

@@ -1,4 +1,4 @@
-// Baseline JPEG (sequential DCT, Huffman, 8 bit) to RGBA8, for the textures and cube maps the reference's scenes
+// Baseline and progressive JPEG (Huffman-coded DCT, 8 bit) to RGBA8, for the textures and cube maps the reference's scenes
 // name (resources/images/*.jpg).  The reference decodes them with stb_image 2.25 (Texture::Load,
 // src/resource/texture.cpp:19-33; Skybox::Load, src/resource/skybox.cpp:30-58), and a texel only equals the
 // reference's if three choices the JPEG standard leaves open are made the same way:
@@ -9,6 +9,8 @@
 //     end samples from the vertical sums alone;
 //   * YCbCr to RGB in 20-bit fixed point whose factors are first rounded to 12 bits, with the Cb term of green
 //     truncated to its upper 16 bits before the sum.
+// A progressive file's coefficients are collected over its scans (spectral selection, successive approximation) and
+// dequantised with the tables in force at the end of the file, in 16-bit arithmetic, before the same inverse DCT.
 // The tests compare with the reference's own decode of every JPEG file it ships and of generated files.
 #include "image_io.hpp"
 
@@ -43,6 +45,7 @@ namespace
         int stride = 0, rows = 0;    // samples allocated: whole MCUs
         int dcPrediction = 0;
         std::vector< uint8_t > plane;
+        std::vector< int16_t > coefficients; // progressive files: 64 per block, stride / 8 blocks per row
     };
 
     uint8_t Clamp8( long long x ) { return x < 0 ? 0 : ( x > 255 ? 255 : static_cast< uint8_t >( x ) ); }
@@ -134,6 +137,7 @@ namespace
         bool Decode( ImageRGBA8& out, std::string& error )
         {
             if ( !ParseHeaders( error ) ) return false;
+            if ( m_progressive ) TransformCollectedBlocks();
             Output( out );
             return true;
         }
@@ -142,7 +146,8 @@ namespace
         const std::vector< uint8_t >& m_data;
         size_t m_pos = 0;
         int m_width = 0, m_height = 0, m_hMax = 1, m_vMax = 1, m_mcusX = 0, m_mcusY = 0, m_restartInterval = 0;
-        bool m_jfif = false;
+        bool m_jfif = false, m_progressive = false;
+        int m_spectralStart = 0, m_spectralEnd = 63, m_approxHigh = 0, m_approxLow = 0, m_endOfBandRun = 0;
         int m_adobeTransform = -1;
         std::vector< Component > m_components;
         uint16_t m_quant[4][64] = {};
@@ -224,13 +229,17 @@ namespace
                         break;
                     case 0xC0: // SOF0, SOF1: sequential, Huffman
                     case 0xC1:
+                        m_progressive = false;
                         if ( !ParseFrame( error ) ) return false;
                         haveFrame = true;
                         break;
-                    case 0xC2:
-                        return Fail( error, "progressive files are not decoded by this host" );
+                    case 0xC2: // SOF2: progressive, Huffman
+                        m_progressive = true;
+                        if ( !ParseFrame( error ) ) return false;
+                        haveFrame = true;
+                        break;
                     case 0xC3: case 0xC5: case 0xC6: case 0xC7: case 0xC9: case 0xCA: case 0xCB: case 0xCD: case 0xCE: case 0xCF:
-                        return Fail( error, "only sequential Huffman-coded DCT files are decoded" );
+                        return Fail( error, "only Huffman-coded sequential and progressive DCT files are decoded" );
                     case 0xDA: // SOS
                         if ( !haveFrame ) return Fail( error, "scan before frame header" );
                         if ( !ParseScan( error ) ) return false;
@@ -275,6 +284,7 @@ namespace
                 c.stride = m_mcusX * c.h * 8;
                 c.rows   = m_mcusY * c.v * 8;
                 c.plane.assign( static_cast< size_t >( c.stride ) * c.rows, 0 );
+                if ( m_progressive ) c.coefficients.assign( static_cast< size_t >( c.stride ) * c.rows, 0 );
             }
             return true;
         }
@@ -344,8 +354,8 @@ namespace
             const uint16_t* q = m_quant[c.quant];
             int size = Symbol( m_dc[c.dcTable] );
             if ( size < 0 || size > 15 ) return false;
-            c.dcPrediction += Extend( size );
-            block[0] = static_cast< int16_t >( c.dcPrediction * q[0] );
+            c.dcPrediction = WrapAdd( c.dcPrediction, Extend( size ) );
+            block[0]       = Int16( WrapMul( c.dcPrediction, q[0] ) );
             for ( int k = 1; k < 64; )
             {
                 const int rs = Symbol( m_ac[c.acTable] );
@@ -365,11 +375,137 @@ namespace
             return true;
         }
 
+        // arithmetic that wraps like the 32- and 16-bit registers it models, whatever a damaged file feeds it
+        static int WrapAdd( int a, int b ) { return static_cast< int >( static_cast< uint32_t >( a ) + static_cast< uint32_t >( b ) ); }
+        static int WrapMul( int a, int b ) { return static_cast< int >( static_cast< uint32_t >( a ) * static_cast< uint32_t >( b ) ); }
+        static int16_t Int16( int a ) { return static_cast< int16_t >( static_cast< uint16_t >( static_cast< uint32_t >( a ) ) ); }
+
+        // DC scan of a progressive file: the first one carries the prediction differences scaled down by 2^low,
+        // a refining one a single further bit per block
+        bool DecodeProgressiveDc( Component& c, int16_t block[64] )
+        {
+            if ( m_approxHigh == 0 )
+            {
+                std::memset( block, 0, 64 * sizeof( int16_t ) );
+                const int size = Symbol( m_dc[c.dcTable] );
+                if ( size < 0 || size > 15 ) return false;
+                c.dcPrediction = WrapAdd( c.dcPrediction, Extend( size ) );
+                block[0]       = Int16( WrapMul( c.dcPrediction, 1 << m_approxLow ) );
+            }
+            else if ( Bits( 1 ) )
+                block[0] = Int16( block[0] + ( 1 << m_approxLow ) );
+            return true;
+        }
+
+        // one more bit of a coefficient that is already non-zero
+        void Refine( int16_t& value, int bit )
+        {
+            if ( Bits( 1 ) && ( value & bit ) == 0 ) value = Int16( value > 0 ? value + bit : value - bit );
+        }
+
+        // AC scan of a progressive file over the band [m_spectralStart, m_spectralEnd] of one block
+        bool DecodeProgressiveAc( const Component& c, int16_t block[64] )
+        {
+            const HuffmanTable& table = m_ac[c.acTable];
+            if ( m_approxHigh == 0 )
+            {
+                if ( m_endOfBandRun )
+                {
+                    --m_endOfBandRun;
+                    return true;
+                }
+                int k = m_spectralStart;
+                do
+                {
+                    const int rs = Symbol( table );
+                    if ( rs < 0 ) return false;
+                    const int run = rs >> 4, bits = rs & 15;
+                    if ( bits == 0 )
+                    {
+                        if ( run < 15 ) // this band ends here, in this block and the next `run length - 1`
+                        {
+                            m_endOfBandRun = ( 1 << run ) + ( run ? Bits( run ) : 0 ) - 1;
+                            break;
+                        }
+                        k += 16;
+                    }
+                    else
+                    {
+                        k += run;
+                        const int at = k < 64 ? kZigZag[k] : 63;
+                        ++k;
+                        block[at] = Int16( WrapMul( Extend( bits ), 1 << m_approxLow ) );
+                    }
+                } while ( k <= m_spectralEnd );
+                return true;
+            }
+
+            const int bit = 1 << m_approxLow;
+            if ( m_endOfBandRun )
+            {
+                --m_endOfBandRun;
+                for ( int k = m_spectralStart; k <= m_spectralEnd; ++k )
+                    if ( block[kZigZag[k]] != 0 ) Refine( block[kZigZag[k]], bit );
+                return true;
+            }
+            int k = m_spectralStart;
+            do
+            {
+                const int rs = Symbol( table );
+                if ( rs < 0 ) return false;
+                int run = rs >> 4, value = 0;
+                if ( ( rs & 15 ) == 0 )
+                {
+                    if ( run < 15 )
+                    {
+                        m_endOfBandRun = ( 1 << run ) - 1 + ( run ? Bits( run ) : 0 );
+                        run            = 64; // no new coefficient in the rest of the band, only refinements
+                    }
+                    // run 15: sixteen zeros, the sixteenth "set" to zero below
+                }
+                else
+                {
+                    if ( ( rs & 15 ) != 1 ) return false;
+                    value = Bits( 1 ) ? bit : -bit;
+                }
+                while ( k <= m_spectralEnd )
+                {
+                    int16_t& coefficient = block[kZigZag[k++]];
+                    if ( coefficient != 0 )
+                        Refine( coefficient, bit );
+                    else if ( run-- == 0 )
+                    {
+                        coefficient = static_cast< int16_t >( value );
+                        break;
+                    }
+                }
+            } while ( k <= m_spectralEnd );
+            return true;
+        }
+
+        // progressive files: dequantise what the scans collected, with 16-bit products, and transform
+        void TransformCollectedBlocks()
+        {
+            for ( Component& c : m_components )
+            {
+                const uint16_t* q = m_quant[c.quant];
+                const int bx = ( c.width + 7 ) / 8, by = ( c.height + 7 ) / 8, perRow = c.stride / 8;
+                for ( int y = 0; y < by; ++y )
+                    for ( int x = 0; x < bx; ++x )
+                    {
+                        int16_t* block = &c.coefficients[64 * ( static_cast< size_t >( y ) * perRow + x )];
+                        for ( int i = 0; i < 64; ++i ) block[i] = Int16( WrapMul( block[i], q[i] ) );
+                        InverseDctBlock( block, &c.plane[static_cast< size_t >( 8 * y ) * c.stride + 8 * x], c.stride );
+                    }
+            }
+        }
+
         void RestartDecoder()
         {
             m_bits = 0;
             m_bitCount = 0;
             m_hitMarker = false;
+            m_endOfBandRun = 0;
             for ( Component& c : m_components ) c.dcPrediction = 0;
         }
 
@@ -387,11 +523,26 @@ namespace
                 if ( !found ) return Fail( error, "scan names an unknown component" );
                 found->dcTable = tables >> 4;
                 found->acTable = tables & 15;
-                if ( found->dcTable > 3 || found->acTable > 3 || !m_dc[found->dcTable].present || !m_ac[found->acTable].present )
-                    return Fail( error, "scan uses a Huffman table that was not defined" );
+                if ( found->dcTable > 3 || found->acTable > 3 ) return Fail( error, "bad Huffman table index" );
                 scan.push_back( found );
             }
-            m_pos += 3; // spectral selection and approximation: fixed for sequential files
+            m_spectralStart = Byte();
+            m_spectralEnd   = Byte();
+            const int approximation = Byte();
+            m_approxHigh = approximation >> 4;
+            m_approxLow  = approximation & 15;
+            if ( m_progressive )
+            {
+                if ( m_spectralStart > 63 || m_spectralEnd > 63 || m_spectralStart > m_spectralEnd || m_approxHigh > 13 || m_approxLow > 13 )
+                    return Fail( error, "bad scan header" );
+                if ( m_spectralStart == 0 ? m_spectralEnd != 0 : n != 1 ) return Fail( error, "DC and AC coefficients in one progressive scan" );
+            }
+            for ( const Component* c : scan )
+            {
+                const bool needsDc = !m_progressive || ( m_spectralStart == 0 && m_approxHigh == 0 ), needsAc = !m_progressive || m_spectralStart != 0;
+                if ( ( needsDc && !m_dc[c->dcTable].present ) || ( needsAc && !m_ac[c->acTable].present ) )
+                    return Fail( error, "scan uses a Huffman table that was not defined" );
+            }
             RestartDecoder();
 
             int16_t block[64];
@@ -419,8 +570,17 @@ namespace
                 for ( int y = 0; y < by; ++y )
                     for ( int x = 0; x < bx; ++x )
                     {
-                        if ( !DecodeBlock( c, block ) ) return Fail( error, "bad Huffman code" );
-                        InverseDctBlock( block, &c.plane[static_cast< size_t >( 8 * y ) * c.stride + 8 * x], c.stride );
+                        if ( m_progressive )
+                        {
+                            int16_t* collected = &c.coefficients[64 * ( static_cast< size_t >( y ) * ( c.stride / 8 ) + x )];
+                            if ( !( m_spectralStart == 0 ? DecodeProgressiveDc( c, collected ) : DecodeProgressiveAc( c, collected ) ) )
+                                return Fail( error, "bad Huffman code" );
+                        }
+                        else
+                        {
+                            if ( !DecodeBlock( c, block ) ) return Fail( error, "bad Huffman code" );
+                            InverseDctBlock( block, &c.plane[static_cast< size_t >( 8 * y ) * c.stride + 8 * x], c.stride );
+                        }
                         if ( !afterUnit() ) goto done;
                     }
             }
@@ -433,8 +593,14 @@ namespace
                             for ( int v = 0; v < c->v; ++v )
                                 for ( int h = 0; h < c->h; ++h )
                                 {
-                                    if ( !DecodeBlock( *c, block ) ) return Fail( error, "bad Huffman code" );
                                     const int x = ( mx * c->h + h ) * 8, y = ( my * c->v + v ) * 8;
+                                    if ( m_progressive ) // only DC scans interleave
+                                    {
+                                        if ( !DecodeProgressiveDc( *c, &c->coefficients[64 * ( static_cast< size_t >( y / 8 ) * ( c->stride / 8 ) + x / 8 )] ) )
+                                            return Fail( error, "bad Huffman code" );
+                                        continue;
+                                    }
+                                    if ( !DecodeBlock( *c, block ) ) return Fail( error, "bad Huffman code" );
                                     InverseDctBlock( block, &c->plane[static_cast< size_t >( y ) * c->stride + x], c->stride );
                                 }
                         if ( !afterUnit() ) goto done;

@@ -84,7 +84,7 @@ def test_image_readers_survive_damaged_files(fuzzer, tmp_path):
     rng = np.random.default_rng(1)
     picture = (rng.integers(0, 4, (40, 50, 3)) * 80).astype(np.float32) / 255
     files = []
-    for ext in ("tga", "bmp", "ppm", "png"):
+    for ext in ("tga", "bmp", "ppm", "png", "jpg"):
         f = str(tmp_path / f"picture.{ext}")
         host.write_image(f, picture)
         files.append(f)
@@ -96,7 +96,9 @@ def test_image_readers_survive_damaged_files(fuzzer, tmp_path):
         img.save(str(tmp_path / "restart.jpg"), quality=70, subsampling=0, restart_marker_blocks=2)
         img.save(str(tmp_path / "deflated.png"), optimize=True)
         img.convert("P").save(str(tmp_path / "palette.png"))
-        files += [str(tmp_path / n) for n in ("rle.tga", "picture.jpg", "restart.jpg", "deflated.png", "palette.png")]
+        img.save(str(tmp_path / "progressive.jpg"), quality=70, progressive=True)
+        img.save(str(tmp_path / "progressive_restart.jpg"), quality=30, progressive=True, subsampling=0, restart_marker_blocks=2)
+        files += [str(tmp_path / n) for n in ("rle.tga", "picture.jpg", "restart.jpg", "deflated.png", "palette.png", "progressive.jpg", "progressive_restart.jpg")]
     except ImportError:
         pass
     for f in files:

@@ -204,8 +204,8 @@ def test_tga_decoding_equals_the_reference_texture_load():
 def test_jpeg_decoding_equals_the_reference_texture_load(tmp_path):
     """Baseline JPEG through the host library and through the reference's Texture::Load (stb_image): the seven
     files the reference ships (4:2:0) and generated ones - 4:4:4, 4:2:2, 4:2:0, grey, odd sizes down to 1 x 1,
-    qualities 5 to 100, optimised Huffman tables, restart markers - equal bytes.  A progressive file is refused
-    with an error (the reference would decode it; none of its scenes has one)."""
+    qualities 5 to 100, optimised Huffman tables, restart markers, and each of those as a progressive file (DC
+    and AC scans with successive approximation, as libjpeg's standard script orders them) - equal bytes."""
     import glob
     files = sorted(glob.glob("/root/reference/resources/**/*.jpg", recursive=True))
     assert len(files) >= 7
@@ -220,7 +220,9 @@ def test_jpeg_decoding_equals_the_reference_texture_load(tmp_path):
         for (w, h) in ((131, 97), (64, 64), (17, 9), (8, 8), (1, 1), (33, 1), (1, 20)):
             img = PIL.fromarray(pic[:h, :w])
             for subsampling in (0, 1, 2):
-                for quality, extra in ((75, {}), (100, {}), (5, {}), (90, {"optimize": True}), (60, {"restart_marker_blocks": 3})):
+                for quality, extra in ((75, {}), (100, {}), (5, {}), (90, {"optimize": True}), (60, {"restart_marker_blocks": 3}),
+                                       (75, {"progressive": True}), (100, {"progressive": True}), (5, {"progressive": True}),
+                                       (60, {"progressive": True, "restart_marker_blocks": 3})):
                     f = str(tmp_path / f"c{n}.jpg")
                     n += 1
                     img.save(f, "JPEG", quality=quality, subsampling=subsampling, **extra)
@@ -229,14 +231,15 @@ def test_jpeg_decoding_equals_the_reference_texture_load(tmp_path):
             n += 1
             img.convert("L").save(f, "JPEG", quality=80)
             files.append(f)
+            f = str(tmp_path / f"gp{n}.jpg")
+            n += 1
+            img.convert("L").save(f, "JPEG", quality=80, progressive=True)
+            files.append(f)
     for f in files:
         for flip in (True, False):
             mine, theirs = host.read_image(f, flip), ref.load_texture(f, flip=flip)
             assert mine.shape == theirs.shape and np.array_equal(mine, theirs), (f, flip)
-    f = str(tmp_path / "progressive.jpg")
-    PIL.fromarray(pictures["smooth"].clip(0, 255).astype(np.uint8)).save(f, "JPEG", progressive=True)
-    with pytest.raises(host.HostError):
-        host.read_image(f, True)
+    assert sum(b"\xff\xc2" in open(f, "rb").read()[:1024] for f in files) >= 250   # progressive frame headers
 
 
 def test_reference_texture_scene_loads_and_renders_bit_identically():
