@@ -68,12 +68,17 @@ int pth_camera_vectors( const float rotation[3], float view[3], float up[3], flo
 int pth_sphere_world_to_local( const float position[3], const float rotation[3], float radius, float out16[16] );
 
 /* Image::Save (src/image.cpp:43-100): quantise W*H*3 floats with 255 * clamp01 truncated and write
- * .png / .tga / .bmp / .ppm. */
+ * .png / .tga / .bmp / .jpg / .jpeg as the reference's writer does, byte for byte, or .ppm. */
 int pth_write_image( const char* filename, const float* rgb, int32_t width, int32_t height );
 
 /* Texture::Load's decode (src/resource/texture.cpp:19-33: stbi_load with four channels, rows flipped when asked):
- * RGBA8, row 0 first.  Call with rgba = NULL to get the size.  TGA, PNG, baseline JPEG, BMP, PPM / PGM. */
+ * RGBA8, row 0 first.  Call with rgba = NULL to get the size.  TGA, PNG, baseline and progressive JPEG, BMP, PPM / PGM. */
 int pth_read_image( const char* filename, int32_t flip_vertically, int32_t* width, int32_t* height, uint8_t* rgba, uint64_t capacity );
+
+/* Skybox::Load's decode of one face (src/resource/skybox.cpp:33-37: stbi_loadf, four channels, hdr gamma and scale
+ * 1): RGBA float, row 0 first; a Radiance .hdr file's radiance, any other format's bytes / 255.  `capacity` in
+ * floats; rgba = NULL to get the size. */
+int pth_read_image_float( const char* filename, int32_t flip_vertically, int32_t* width, int32_t* height, float* rgba, uint64_t capacity );
 
 const char* pth_last_error( void );
 

@@ -95,6 +95,15 @@ def load_texture(filename, flip=True):
     return px
 
 
+def load_skybox_face(filename, flip=True):
+    """One cube map face as Skybox::Load decodes it (stbi_loadf, 4 channels, hdr scale and gamma 1): (h, w, 4) floats."""
+    w, h = C.c_int32(0), C.c_int32(0)
+    _check(lib().ref_load_skybox_face(filename.encode(), int(flip), C.byref(w), C.byref(h), None, C.c_uint64(0)))
+    px = np.zeros((h.value, w.value, 4), np.float32)
+    _check(lib().ref_load_skybox_face(filename.encode(), int(flip), C.byref(w), C.byref(h), _p(px), C.c_uint64(px.size)))
+    return px
+
+
 def save_image(filename, rgb):
     """The reference's Image::Save (quantiser + stb_image_write) on an (h, w, 3) float picture."""
     rgb = _f32(rgb)

@@ -19,6 +19,7 @@
 // covered by this harness.
 #include "bvh.hpp"
 #include "image.hpp"
+#include "stb_image/stb_image.h"
 #include "anti_aliasing.hpp"
 #include "intersection_tests.hpp"
 #include "lights.hpp"
@@ -386,6 +387,29 @@ int ref_load_texture( const char* filename, int flipVertically, int32_t* width, 
         std::memcpy( rgba, tex.GetPixels(), bytes );
     }
     return 0;
+}
+
+// Decodes one cube map face with the calls Skybox::Load makes (src/resource/skybox.cpp:33-37; that file itself
+// needs the cmake-generated configuration header and is not part of this build): the reference's stb_image,
+// stbi_loadf with four channels, hdr scale and gamma set to 1.
+int ref_load_skybox_face( const char* filename, int flipVertically, int32_t* width, int32_t* height, float* rgba, uint64_t capacity )
+{
+    stbi_set_flip_vertically_on_load( flipVertically != 0 );
+    stbi_ldr_to_hdr_scale( 1.0f );
+    stbi_ldr_to_hdr_gamma( 1.0f );
+    int w, h, nc;
+    float* pixels = stbi_loadf( filename, &w, &h, &nc, 4 );
+    if ( !pixels ) return Fail( std::string( "stbi_loadf failed for " ) + filename );
+    *width  = w;
+    *height = h;
+    int rc  = 0;
+    if ( rgba )
+    {
+        if ( static_cast< uint64_t >( w ) * h * 4 > capacity ) rc = Fail( "ref_load_skybox_face: buffer too small" );
+        else std::memcpy( rgba, pixels, static_cast< size_t >( w ) * h * 16 );
+    }
+    stbi_image_free( pixels );
+    return rc;
 }
 
 // ---- scenes ------------------------------------------------------------------------------------------

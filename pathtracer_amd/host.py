@@ -38,6 +38,7 @@ def lib():
         L.pth_sphere_world_to_local.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
         L.pth_write_image.argtypes = [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32]
         L.pth_read_image.argtypes = [C.c_char_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_void_p, C.c_uint64]
+        L.pth_read_image_float.argtypes = [C.c_char_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_void_p, C.c_uint64]
         L.pth_last_error.restype = C.c_char_p
         _LIB = L
     return _LIB
@@ -154,6 +155,15 @@ def read_image(filename, flip=True):
     _check(lib().pth_read_image(filename.encode(), int(flip), C.byref(w), C.byref(h), None, 0))
     px = np.zeros((h.value, w.value, 4), np.uint8)
     _check(lib().pth_read_image(filename.encode(), int(flip), C.byref(w), C.byref(h), px.ctypes.data, px.nbytes))
+    return px
+
+
+def read_image_float(filename, flip=True):
+    """RGBA float pixels (h, w, 4) as Skybox::Load decodes a face (src/resource/skybox.cpp:33-37)."""
+    w, h = C.c_int32(0), C.c_int32(0)
+    _check(lib().pth_read_image_float(filename.encode(), int(flip), C.byref(w), C.byref(h), None, 0))
+    px = np.zeros((h.value, w.value, 4), np.float32)
+    _check(lib().pth_read_image_float(filename.encode(), int(flip), C.byref(w), C.byref(h), px.ctypes.data, px.size))
     return px
 
 

@@ -220,6 +220,25 @@ int pth_read_image( const char* filename, int32_t flip_vertically, int32_t* widt
     } );
 }
 
+int pth_read_image_float( const char* filename, int32_t flip_vertically, int32_t* width, int32_t* height, float* rgba, uint64_t capacity )
+{
+    if ( !filename || !width || !height ) return Fail( "pth_read_image_float: bad argument" );
+    return Guard( [&] {
+        std::vector< float > pixels;
+        std::string err;
+        int w = 0, h = 0;
+        if ( !pth::ReadImageRGBA32F( filename, flip_vertically != 0, w, h, pixels, err ) ) return Fail( err );
+        *width  = w;
+        *height = h;
+        if ( rgba )
+        {
+            if ( capacity < pixels.size() ) return Fail( "pth_read_image_float: buffer too small" );
+            std::memcpy( rgba, pixels.data(), pixels.size() * sizeof( float ) );
+        }
+        return 0;
+    } );
+}
+
 const char* pth_last_error( void ) { return g_error.c_str(); }
 
 } // extern "C"

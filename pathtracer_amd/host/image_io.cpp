@@ -415,7 +415,7 @@ bool ReadImageRGBA8( const std::string& filename, bool flipVertically, ImageRGBA
     else if ( f.size() > 2 && f[0] == 0xFF && f[1] == 0xD8 ) ok = ReadJpegRGBA8( filename, out, error );
     else if ( f.size() > 4 && f[0] == 0x89 && f[1] == 'P' && f[2] == 'N' && f[3] == 'G' ) ok = ReadPngRGBA8( f, out, error );
     else if ( ext == "tga" ) ok = ReadTga( f, out, error );
-    else error = "image format of '" + filename + "' is not decoded by this host (TGA, PNG, baseline JPEG, BMP, PPM only)";
+    else error = "image format of '" + filename + "' is not decoded by this host (TGA, PNG, JPEG, BMP, PPM only)";
     if ( !ok )
     {
         error = "Failed to load image '" + filename + "': " + error;
@@ -427,6 +427,39 @@ bool ReadImageRGBA8( const std::string& filename, bool flipVertically, ImageRGBA
         for ( int r = 0; r < out.height / 2; ++r )
             std::swap_ranges( out.pixels.begin() + row * r, out.pixels.begin() + row * ( r + 1 ),
                               out.pixels.begin() + row * ( out.height - 1 - r ) );
+    }
+    return true;
+}
+
+bool ReadImageRGBA32F( const std::string& filename, bool flipVertically, int& width, int& height, std::vector< float >& pixels, std::string& error )
+{
+    std::vector< uint8_t > f;
+    if ( !ReadFile( filename, f ) )
+    {
+        error = "Failed to load image '" + filename + "'";
+        return false;
+    }
+    if ( !IsRadianceFile( f ) )
+    {
+        f.clear();
+        ImageRGBA8 bytes;
+        if ( !ReadImageRGBA8( filename, flipVertically, bytes, error ) ) return false;
+        width  = bytes.width;
+        height = bytes.height;
+        pixels.resize( bytes.pixels.size() );
+        for ( size_t i = 0; i < pixels.size(); ++i ) pixels[i] = bytes.pixels[i] / 255.0f;
+        return true;
+    }
+    if ( !ReadRadianceRGBA32F( f, width, height, pixels, error ) )
+    {
+        error = "Failed to load image '" + filename + "': " + error;
+        return false;
+    }
+    if ( flipVertically )
+    {
+        const size_t row = static_cast< size_t >( width ) * 4;
+        for ( int r = 0; r < height / 2; ++r )
+            std::swap_ranges( pixels.begin() + row * r, pixels.begin() + row * ( r + 1 ), pixels.begin() + row * ( height - 1 - r ) );
     }
     return true;
 }

@@ -21,6 +21,13 @@ struct ImageRGBA8
 // (jpeg_decoder.cpp).
 bool ReadImageRGBA8( const std::string& filename, bool flipVertically, ImageRGBA8& out, std::string& error );
 
+// A picture as floats, the way the reference loads cube map faces (stbi_loadf with its gamma and scale set to 1,
+// src/resource/skybox.cpp:33-37): a Radiance .hdr file's radiance as stored (hdr_decoder.cpp), any other format's
+// bytes divided by 255.  RGBA, row 0 first, rows flipped if asked.
+bool ReadImageRGBA32F( const std::string& filename, bool flipVertically, int& width, int& height, std::vector< float >& pixels, std::string& error );
+bool IsRadianceFile( const std::vector< uint8_t >& file );
+bool ReadRadianceRGBA32F( const std::vector< uint8_t >& file, int& width, int& height, std::vector< float >& pixels, std::string& error );
+
 // Baseline or progressive JPEG with the arithmetic of the reference's decoder (jpeg_decoder.cpp); rows as stored, top row first.
 bool ReadJpegRGBA8( const std::string& filename, ImageRGBA8& out, std::string& error );
 

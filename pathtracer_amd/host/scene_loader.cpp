@@ -201,21 +201,22 @@ bool LoadSceneFile( HostScene& scene, const std::string& filename, const SceneLo
             int w = 0, h = 0;
             for ( int f = 0; f < 6; ++f ) // Skybox::Load, src/resource/skybox.cpp:19-61
             {
-                ImageRGBA8 img;
+                std::vector< float > face;
                 std::string err;
-                if ( !ReadImageRGBA8( opts.resourceDir + faces[f], flip, img, err ) )
+                int fw = 0, fh = 0;
+                // stbi_loadf with hdr scale and gamma forced to 1: byte / 255, or a Radiance file's own floats
+                if ( !ReadImageRGBA32F( opts.resourceDir + faces[f], flip, fw, fh, face, err ) )
                 {
                     if ( log ) log( "ERROR    " + err );
                     return;
                 }
-                if ( f == 0 ) { w = img.width; h = img.height; }
-                if ( img.width != w || img.height != h )
+                if ( f == 0 ) { w = fw; h = fh; }
+                if ( fw != w || fh != h )
                 {
                     if ( log ) log( "ERROR    skybox faces differ in size" );
                     return;
                 }
-                // stbi_loadf on an LDR file with hdr scale and gamma forced to 1: byte / 255
-                for ( uint8_t b : img.pixels ) pixels.push_back( b / 255.0f );
+                pixels.insert( pixels.end(), face.begin(), face.end() );
             }
             scene.skybox       = std::move( pixels );
             scene.skyboxWidth  = w;

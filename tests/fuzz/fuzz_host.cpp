@@ -1,6 +1,6 @@
 // Damaged input files through the host library's readers, built with -fsanitize=address,undefined by
 // tests/test_fuzz_host.py: whatever the bytes, a reader returns an image / a scene or an error message.
-//   fuzz_host image FILE ITERATIONS          mutates FILE (TGA, BMP, PPM, JPEG) and decodes it
+//   fuzz_host image FILE ITERATIONS          mutates FILE (TGA, BMP, PPM, JPEG, PNG, HDR) and decodes it
 //   fuzz_host scene DIR ITERATIONS           DIR holds scenes/base.json and the model files it names, writable
 #include "image_io.hpp"
 #include "scene_loader.hpp"
@@ -58,8 +58,15 @@ int main( int argc, char** argv )
             std::vector< char > bytes = original;
             Damage( bytes, rng, 64, false );
             Spit( copy, bytes );
-            pth::ImageRGBA8 image;
             std::string error;
+            if ( copy.size() > 4 && copy.substr( copy.size() - 4 ) == ".hdr" )
+            {
+                std::vector< float > pixels;
+                int w = 0, h = 0;
+                ( pth::ReadImageRGBA32F( copy, true, w, h, pixels, error ) ? accepted : refused )++;
+                continue;
+            }
+            pth::ImageRGBA8 image;
             ( pth::ReadImageRGBA8( copy, true, image, error ) ? accepted : refused )++;
         }
     }

@@ -88,6 +88,10 @@ def test_image_readers_survive_damaged_files(fuzzer, tmp_path):
         f = str(tmp_path / f"picture.{ext}")
         host.write_image(f, picture)
         files.append(f)
+    from hdr_writer import to_rgbe, write_hdr
+    for run_length in (True, False):
+        files.append(str(tmp_path / f"radiance{int(run_length)}.hdr"))
+        write_hdr(files[-1], to_rgbe(picture * 50), run_length)
     try:
         import PIL.Image
         img = PIL.Image.fromarray((picture * 255).astype(np.uint8))

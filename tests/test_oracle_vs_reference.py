@@ -376,3 +376,51 @@ def test_image_writers_equal_the_reference_image_save(ext, tmp_path):
             assert np.abs(back.astype(int) - quantised).mean() < 6
         else:
             assert np.array_equal(back, quantised), (ext, n)
+
+
+def test_cube_map_face_decoding_equals_the_reference_float_load(tmp_path):
+    """A cube map face through the host library and through the calls Skybox::Load makes (stbi_loadf, four
+    channels, gamma and scale 1, src/resource/skybox.cpp:33-37): Radiance .hdr files - run-length coded and flat,
+    widths on both sides of the 8-pixel limit of the run-length coding, both identifier lines, black pixels with
+    a zero exponent, radiance from 1e-6 to 1e6 - give the same floats bit for bit, flipped or not; so do 8-bit
+    formats (byte / 255).  A scene whose Skybox names six .hdr faces loads them in the reference's order."""
+    from hdr_writer import to_rgbe, write_hdr
+    rng = np.random.default_rng(6)
+    files = []
+    for n, (w, h) in enumerate(((40, 12), (8, 5), (7, 9), (1, 1), (300, 3), (129, 4))):
+        radiance = np.exp(rng.uniform(np.log(1e-6), np.log(1e6), (h, w, 1))) * rng.uniform(0, 1, (h, w, 3))
+        radiance[h // 2:, : w // 2] = radiance[h // 2, 0]      # runs
+        radiance[0, 0] = 0                                     # zero exponent byte
+        rgbe = to_rgbe(radiance)
+        for run_length in (True, False):
+            for identifier in ("#?RADIANCE", "#?RGBE"):
+                files.append(str(tmp_path / f"{n}_{int(run_length)}_{identifier[2:]}.hdr"))
+                write_hdr(files[-1], rgbe, run_length, identifier)
+    picture = rng.uniform(0, 1, (9, 14, 3)).astype(np.float32)
+    for ext in ("png", "tga", "bmp", "jpg"):
+        files.append(str(tmp_path / f"ldr.{ext}"))
+        host.write_image(files[-1], picture)
+    seen_large = False
+    for f in files:
+        for flip in (True, False):
+            mine, theirs = host.read_image_float(f, flip), ref.load_skybox_face(f, flip)
+            assert mine.shape == theirs.shape and mine.tobytes() == theirs.tobytes(), (f, flip)
+            seen_large |= bool(mine[..., :3].max() > 100)
+    assert seen_large
+    with open(tmp_path / "truncated.hdr", "wb") as f:
+        f.write(open(files[0], "rb").read()[:90])
+    with pytest.raises(host.HostError):
+        host.read_image_float(str(tmp_path / "truncated.hdr"))
+
+    names = ("right", "left", "top", "bottom", "back", "front")
+    for k, name in enumerate(names):
+        write_hdr(str(tmp_path / f"{name}.hdr"), to_rgbe(np.full((16, 16, 3), 0.25 * (k + 1)) + rng.uniform(0, 30, (16, 16, 3))))
+    (tmp_path / "sky.json").write_text('{ "Skybox": { "name": "sky", ' + ", ".join(f'"{n}": "{n}.hdr"' for n in names) + ''' },
+      "Material": { "name": "grey", "albedo": [ 0.5, 0.5, 0.5 ] },
+      "Sphere": { "material": "grey", "position": [ 0, 0, -5 ], "radius": 1 } }''')
+    with host.HostScene.from_file(str(tmp_path / "sky.json"), str(tmp_path) + "/") as hs:
+        scene = hs.to_data()
+    faces = scene.skybox.reshape(6, 16, 16, 4)
+    for k, name in enumerate(names):
+        assert np.array_equal(faces[k], ref.load_skybox_face(str(tmp_path / f"{name}.hdr"), True)), name
+    assert faces.max() > 20
