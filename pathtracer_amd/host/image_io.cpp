@@ -128,37 +128,171 @@ namespace
         return true;
     }
 
+    // A `bits`-wide field that was moved so that its top bit is bit 7, widened to eight bits by repeating it
+    // (stb_image's stbi__shiftsigned: multiply-and-shift tables per width).
+    int WidenField( uint32_t v, int shift, int bits )
+    {
+        static const uint32_t multiplier[9] = { 0, 0xff, 0x55, 0x49, 0x11, 0x21, 0x41, 0x81, 0x01 };
+        static const int shiftBack[9]       = { 0, 0, 0, 1, 0, 2, 4, 6, 0 };
+        if ( shift < 0 ) v <<= -shift;
+        else v >>= shift;
+        v &= 0xff;
+        v >>= ( 8 - bits );
+        return static_cast< int >( v * multiplier[bits] ) >> shiftBack[bits];
+    }
+
+    int HighBit( uint32_t v )
+    {
+        int n = -1;
+        for ( ; v; v >>= 1 ) ++n;
+        return n;
+    }
+
+    int BitCount( uint32_t v )
+    {
+        int n = 0;
+        for ( ; v; v >>= 1 ) n += v & 1;
+        return n;
+    }
+
+    // Windows / OS2 bitmaps as the reference's decoder reads them (stb_image 2.25 behind Texture::Load,
+    // src/resource/texture.cpp:19-33): core (12 byte), info (40, 56), V4 and V5 headers; 1, 4 and 8 bit with a
+    // palette, 16 and 32 bit through channel masks (5-5-5 and 8-8-8-8 by default, BI_BITFIELDS otherwise), 24 bit;
+    // no run-length compression; rows bottom-up unless the height is negative; a 32 bit file under a 40 or 56 byte
+    // header whose alpha bytes are all zero is opaque.
     bool ReadBmp( const std::vector< uint8_t >& f, ImageRGBA8& out, std::string& error )
     {
-        auto u32 = [&]( size_t o ) { return static_cast< uint32_t >( f[o] | ( f[o + 1] << 8 ) | ( f[o + 2] << 16 ) | ( f[o + 3] << 24 ) ); };
-        if ( f.size() < 54 ) { error = "BMP header truncated"; return false; }
-        const uint32_t dataOffset = u32( 10 );
-        const int32_t w = static_cast< int32_t >( u32( 18 ) ), hRaw = static_cast< int32_t >( u32( 22 ) );
-        const int bpp = f[28] | ( f[29] << 8 );
-        const uint32_t compression = u32( 30 );
-        if ( compression != 0 || !( bpp == 24 || bpp == 32 ) || w <= 0 || hRaw == 0 )
+        size_t pos = 0;
+        auto u8  = [&]() -> uint32_t { return pos < f.size() ? f[pos++] : 0; };
+        auto u16 = [&]() -> uint32_t { uint32_t lo = u8(); return lo | u8() << 8; };
+        auto u32 = [&]() -> uint32_t { uint32_t lo = u16(); return lo | u16() << 16; };
+        auto fail = [&]( const char* what ) { error = what; return false; };
+        pos = 10;
+        const int offset = static_cast< int >( u32() ), headerSize = static_cast< int >( u32() );
+        if ( headerSize != 12 && headerSize != 40 && headerSize != 56 && headerSize != 108 && headerSize != 124 ) return fail( "unknown BMP header" );
+        int w, hRaw;
+        if ( headerSize == 12 ) { w = static_cast< int >( u16() ); hRaw = static_cast< int >( u16() ); }
+        else { w = static_cast< int32_t >( u32() ); hRaw = static_cast< int32_t >( u32() ); }
+        if ( u16() != 1 ) return fail( "bad BMP (planes)" );
+        const int bpp = static_cast< int >( u16() );
+        uint32_t maskR = 0, maskG = 0, maskB = 0, maskA = 0, alphaSeen = 255;
+        int headerRead = 14;
+        if ( headerSize != 12 )
         {
-            error = "unsupported BMP (only uncompressed 24/32 bit)";
-            return false;
+            const uint32_t compression = u32();
+            if ( compression == 1 || compression == 2 ) return fail( "run-length compressed BMP is not decoded" );
+            pos += 20; // image size, resolution, colour counts
+            if ( headerSize == 40 || headerSize == 56 )
+            {
+                if ( headerSize == 56 ) pos += 16;
+                if ( bpp == 16 || bpp == 32 )
+                {
+                    if ( compression == 0 )
+                    {
+                        if ( bpp == 32 ) { maskR = 0xffu << 16; maskG = 0xffu << 8; maskB = 0xffu; maskA = 0xffu << 24; alphaSeen = 0; }
+                        else { maskR = 31u << 10; maskG = 31u << 5; maskB = 31u; }
+                    }
+                    else if ( compression == 3 )
+                    {
+                        maskR = u32(); maskG = u32(); maskB = u32();
+                        headerRead += 12;
+                        if ( maskR == maskG && maskG == maskB ) return fail( "bad BMP (masks)" );
+                    }
+                    else return fail( "bad BMP (compression)" );
+                }
+            }
+            else
+            {
+                maskR = u32(); maskG = u32(); maskB = u32(); maskA = u32();
+                pos += 4 + 48 + ( headerSize == 124 ? 16 : 0 );
+            }
         }
+        const bool bottomUp = hRaw > 0;
         const int h = hRaw < 0 ? -hRaw : hRaw;
-        const size_t stride = ( static_cast< size_t >( w ) * ( bpp / 8 ) + 3 ) & ~size_t( 3 );
-        if ( dataOffset + stride * h > f.size() ) { error = "BMP data truncated"; return false; }
+        if ( w <= 0 || h <= 0 || w > ( 1 << 24 ) || h > ( 1 << 24 ) ) return fail( "bad BMP size" );
+        int paletteSize = 0;
+        if ( headerSize == 12 ) { if ( bpp < 24 ) paletteSize = ( offset - headerRead - 12 ) / 3; } // three-byte entries
+        else if ( bpp < 16 ) paletteSize = ( offset - headerRead - headerSize ) >> 2;
+        if ( bpp != 1 && bpp != 4 && bpp != 8 && bpp != 16 && bpp != 24 && bpp != 32 ) return fail( "bad BMP bit depth" );
+        const size_t rowBytes = ( ( static_cast< size_t >( w ) * bpp + 7 ) / 8 + 3 ) & ~size_t( 3 );
+        if ( offset < 0 || static_cast< size_t >( offset ) > f.size() || rowBytes * h > f.size() - static_cast< size_t >( offset ) ) return fail( "BMP data truncated" );
         out.width  = w;
         out.height = h;
-        out.pixels.resize( static_cast< size_t >( w ) * h * 4 );
-        for ( int r = 0; r < h; ++r )
+        out.pixels.assign( static_cast< size_t >( w ) * h * 4, 255 );
+        uint8_t* o = out.pixels.data();
+        if ( bpp < 16 )
         {
-            const int srcRow = hRaw < 0 ? r : h - 1 - r;
-            const uint8_t* src = &f[dataOffset + stride * srcRow];
-            for ( int c = 0; c < w; ++c )
+            if ( paletteSize <= 0 || paletteSize > 256 ) return fail( "bad BMP palette" );
+            uint8_t palette[256][3] = {};
+            for ( int i = 0; i < paletteSize; ++i )
             {
-                uint8_t* d = &out.pixels[4 * ( static_cast< size_t >( r ) * w + c )];
-                d[0] = src[c * ( bpp / 8 ) + 2];
-                d[1] = src[c * ( bpp / 8 ) + 1];
-                d[2] = src[c * ( bpp / 8 ) + 0];
-                d[3] = bpp == 32 ? src[c * 4 + 3] : 255;
+                palette[i][2] = static_cast< uint8_t >( u8() );
+                palette[i][1] = static_cast< uint8_t >( u8() );
+                palette[i][0] = static_cast< uint8_t >( u8() );
+                if ( headerSize != 12 ) u8();
             }
+            for ( int j = 0; j < h; ++j )
+            {
+                const uint8_t* row = &f[offset + rowBytes * j];
+                for ( int i = 0; i < w; ++i, o += 4 )
+                {
+                    int index;
+                    if ( bpp == 1 ) index = ( row[i >> 3] >> ( 7 - ( i & 7 ) ) ) & 1;
+                    else if ( bpp == 4 ) index = ( i & 1 ) ? row[i >> 1] & 15 : row[i >> 1] >> 4;
+                    else index = row[i];
+                    o[0] = palette[index][0];
+                    o[1] = palette[index][1];
+                    o[2] = palette[index][2];
+                }
+            }
+        }
+        else
+        {
+            const bool plain = bpp == 24 || ( bpp == 32 && maskB == 0xff && maskG == 0xff00 && maskR == 0x00ff0000 && maskA == 0xff000000 );
+            int shiftR = 0, shiftG = 0, shiftB = 0, shiftA = 0, bitsR = 0, bitsG = 0, bitsB = 0, bitsA = 0;
+            if ( !plain )
+            {
+                if ( !maskR || !maskG || !maskB ) return fail( "bad BMP (masks)" );
+                shiftR = HighBit( maskR ) - 7; bitsR = BitCount( maskR );
+                shiftG = HighBit( maskG ) - 7; bitsG = BitCount( maskG );
+                shiftB = HighBit( maskB ) - 7; bitsB = BitCount( maskB );
+                shiftA = HighBit( maskA ) - 7; bitsA = BitCount( maskA );
+                if ( bitsR > 8 || bitsG > 8 || bitsB > 8 || bitsA > 8 ) return fail( "bad BMP (masks)" );
+            }
+            for ( int j = 0; j < h; ++j )
+            {
+                const uint8_t* p = &f[offset + rowBytes * j];
+                for ( int i = 0; i < w; ++i, o += 4 )
+                {
+                    if ( plain )
+                    {
+                        o[2] = p[0];
+                        o[1] = p[1];
+                        o[0] = p[2];
+                        o[3] = bpp == 32 ? p[3] : 255;
+                        p += bpp / 8;
+                    }
+                    else
+                    {
+                        uint32_t v = p[0] | p[1] << 8;
+                        if ( bpp == 32 ) v |= static_cast< uint32_t >( p[2] ) << 16 | static_cast< uint32_t >( p[3] ) << 24;
+                        p += bpp / 8;
+                        o[0] = static_cast< uint8_t >( WidenField( v & maskR, shiftR, bitsR ) );
+                        o[1] = static_cast< uint8_t >( WidenField( v & maskG, shiftG, bitsG ) );
+                        o[2] = static_cast< uint8_t >( WidenField( v & maskB, shiftB, bitsB ) );
+                        o[3] = static_cast< uint8_t >( maskA ? WidenField( v & maskA, shiftA, bitsA ) : 255 );
+                    }
+                    alphaSeen |= o[3];
+                }
+            }
+        }
+        if ( alphaSeen == 0 )
+            for ( size_t i = 3; i < out.pixels.size(); i += 4 ) out.pixels[i] = 255;
+        if ( bottomUp )
+        {
+            const size_t row = static_cast< size_t >( w ) * 4;
+            for ( int r = 0; r < h / 2; ++r )
+                std::swap_ranges( out.pixels.begin() + row * r, out.pixels.begin() + row * ( r + 1 ), out.pixels.begin() + row * ( h - 1 - r ) );
         }
         return true;
     }
