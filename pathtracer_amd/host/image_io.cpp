@@ -32,56 +32,120 @@ namespace
         return static_cast< bool >( in );
     }
 
+    // Truevision TGA as the reference's decoder reads it (stb_image 2.25 behind Texture::Load,
+    // src/resource/texture.cpp:19-33): true colour 24 / 32 bit, 15 / 16 bit as 5-5-5 without alpha (each field
+    // times 255 / 31, truncated), grey 8 bit, grey with alpha 16 bit, colour-mapped with 8 or 16 bit indices into a
+    // palette of any of those formats (an 8 bit palette entry is a grey level; an index past the palette means
+    // entry 0; the "first entry" field counts bytes to skip before the palette), each raw or run-length coded with
+    // packets that may run across rows; bottom row first unless bit 5 of the descriptor is set.
     bool ReadTga( const std::vector< uint8_t >& f, ImageRGBA8& out, std::string& error )
     {
-        if ( f.size() < 18 ) { error = "TGA header truncated"; return false; }
-        const int idLength = f[0], colorMapType = f[1], type = f[2];
+        auto fail = [&]( const char* what ) { error = what; return false; };
+        if ( f.size() < 18 ) return fail( "TGA header truncated" );
+        const int idLength = f[0], indexed = f[1];
+        int type = f[2];
+        const int paletteStart = f[3] | ( f[4] << 8 ), paletteLength = f[5] | ( f[6] << 8 ), paletteBits = f[7];
         const int width = f[12] | ( f[13] << 8 ), height = f[14] | ( f[15] << 8 );
         const int bpp = f[16], descriptor = f[17];
-        if ( colorMapType != 0 || !( type == 2 || type == 3 || type == 10 || type == 11 ) )
-        {
-            error = "unsupported TGA type (colour-mapped images are not handled)";
-            return false;
-        }
-        const int bytes = bpp / 8;
-        if ( !( bytes == 1 || bytes == 3 || bytes == 4 ) || width <= 0 || height <= 0 )
-        {
-            error = "unsupported TGA pixel depth";
-            return false;
-        }
+        if ( indexed > 1 ) return fail( "bad TGA colour map type" );
+        const bool rle = type >= 8;
+        if ( rle ) type -= 8;
+        if ( indexed ? type != 1 : ( type != 2 && type != 3 ) ) return fail( "unsupported TGA image type" );
+        if ( indexed && bpp != 8 && bpp != 16 ) return fail( "unsupported TGA index size" );
+        if ( width <= 0 || height <= 0 ) return fail( "empty TGA picture" );
+
+        // 1: grey, 2: grey + alpha, 3: colour, 4: colour + alpha; 15 / 16 bit colour is unpacked to three bytes
+        const int formatBits = indexed ? paletteBits : bpp;
+        int channels = 0;
+        bool packed16 = false;
+        if ( formatBits == 8 ) channels = 1;
+        else if ( formatBits == 16 && !indexed && type == 3 ) channels = 2;
+        else if ( formatBits == 15 || formatBits == 16 ) { channels = 3; packed16 = true; }
+        else if ( formatBits == 24 || formatBits == 32 ) channels = formatBits / 8;
+        else return fail( "unsupported TGA pixel depth" );
+
         size_t pos = 18 + static_cast< size_t >( idLength );
-        out.width  = width;
-        out.height = height;
-        out.pixels.assign( static_cast< size_t >( width ) * height * 4, 255 );
-        const bool rle = type >= 10;
-        const size_t total = static_cast< size_t >( width ) * height;
-        size_t i = 0;
-        uint8_t px[4] = { 0, 0, 0, 255 };
-        auto fetch = [&]() -> bool
+        // reads one pixel or palette entry in the file's format into `to` (colour ends up as R, G, B[, A])
+        auto readEntry = [&]( uint8_t* to ) -> bool
         {
-            if ( pos + bytes > f.size() ) return false;
-            if ( bytes == 1 ) { px[0] = px[1] = px[2] = f[pos]; px[3] = 255; }
-            else { px[2] = f[pos]; px[1] = f[pos + 1]; px[0] = f[pos + 2]; px[3] = bytes == 4 ? f[pos + 3] : 255; }
-            pos += bytes;
+            if ( packed16 )
+            {
+                if ( pos + 2 > f.size() ) return false;
+                const int v = f[pos] | ( f[pos + 1] << 8 );
+                pos += 2;
+                to[0] = static_cast< uint8_t >( ( ( v >> 10 ) & 31 ) * 255 / 31 );
+                to[1] = static_cast< uint8_t >( ( ( v >> 5 ) & 31 ) * 255 / 31 );
+                to[2] = static_cast< uint8_t >( ( v & 31 ) * 255 / 31 );
+                return true;
+            }
+            if ( pos + channels > f.size() ) return false;
+            for ( int k = 0; k < channels; ++k ) to[k] = f[pos + k];
+            if ( channels >= 3 ) std::swap( to[0], to[2] ); // stored blue first
+            pos += channels;
             return true;
         };
-        while ( i < total )
+        std::vector< uint8_t > palette;
+        if ( indexed )
         {
-            int run = 1;
-            bool repeat = false;
+            pos += paletteStart;
+            palette.assign( static_cast< size_t >( paletteLength ) * channels + 4, 0 );
+            for ( int i = 0; i < paletteLength; ++i )
+                if ( !readEntry( &palette[static_cast< size_t >( i ) * channels] ) ) return fail( "TGA palette truncated" );
+        }
+        const size_t total = static_cast< size_t >( width ) * height;
+        if ( total / 128 > f.size() ) return fail( "TGA data truncated" ); // a packet of two bytes or more yields at most 128 pixels
+        out.width  = width;
+        out.height = height;
+        out.pixels.assign( total * 4, 255 );
+        uint8_t raw[4]  = { 0, 0, 0, 0 };
+        int packetLeft  = 0;
+        bool repeating  = false, readNext = true;
+        for ( size_t i = 0; i < total; ++i )
+        {
             if ( rle )
             {
-                if ( pos >= f.size() ) { error = "TGA data truncated"; return false; }
-                int header = f[pos++];
-                run        = ( header & 0x7f ) + 1;
-                repeat     = ( header & 0x80 ) != 0;
-                if ( repeat && !fetch() ) { error = "TGA data truncated"; return false; }
+                if ( packetLeft == 0 )
+                {
+                    if ( pos >= f.size() ) return fail( "TGA data truncated" );
+                    const int command = f[pos++];
+                    packetLeft        = 1 + ( command & 127 );
+                    repeating         = ( command >> 7 ) != 0;
+                    readNext          = true;
+                }
+                else if ( !repeating )
+                    readNext = true;
             }
-            for ( int k = 0; k < run && i < total; ++k, ++i )
+            else
+                readNext = true;
+            if ( readNext )
             {
-                if ( !repeat && !fetch() ) { error = "TGA data truncated"; return false; }
-                std::memcpy( &out.pixels[4 * i], px, 4 );
+                if ( indexed )
+                {
+                    const int indexBytes = bpp / 8;
+                    if ( pos + indexBytes > f.size() ) return fail( "TGA data truncated" );
+                    int index = indexBytes == 1 ? f[pos] : f[pos] | ( f[pos + 1] << 8 );
+                    pos += indexBytes;
+                    if ( index >= paletteLength ) index = 0;
+                    for ( int k = 0; k < channels; ++k ) raw[k] = palette[static_cast< size_t >( index ) * channels + k];
+                }
+                else if ( !readEntry( raw ) )
+                    return fail( "TGA data truncated" );
+                readNext = false;
             }
+            uint8_t* o = &out.pixels[4 * i];
+            if ( channels <= 2 )
+            {
+                o[0] = o[1] = o[2] = raw[0];
+                if ( channels == 2 ) o[3] = raw[1];
+            }
+            else
+            {
+                o[0] = raw[0];
+                o[1] = raw[1];
+                o[2] = raw[2];
+                if ( channels == 4 ) o[3] = raw[3];
+            }
+            --packetLeft;
         }
         const bool topOrigin = ( descriptor & 0x20 ) != 0;
         if ( !topOrigin ) // stored bottom row first: bring the top row to the front

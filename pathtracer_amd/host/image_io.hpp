@@ -14,7 +14,7 @@ struct ImageRGBA8
     std::vector< uint8_t > pixels; // 4 bytes per pixel, row 0 first
 };
 
-// Reads TGA (types 2, 3, 10, 11; 8/24/32 bit), binary PPM/PGM (P5, P6) and uncompressed BMP (1 to 32 bit) into
+// Reads TGA (true colour, grey and colour-mapped, raw and run-length coded, 8 to 32 bit), binary PPM/PGM (P5, P6) and uncompressed BMP (1 to 32 bit) into
 // RGBA8 with the top row first, then flips the rows if `flipVertically` - the contract of
 // stbi_load(..., 4) with stbi_set_flip_vertically_on_load as used by Texture::Load
 // (src/resource/texture.cpp:19-33).  Also PNG (png_decoder.cpp) and baseline or progressive JPEG

@@ -507,3 +507,63 @@ def test_bmp_decoding_equals_the_reference_texture_load(tmp_path):
     open(tmp_path / "rle.bmp", "wb").write(bmp(4, 4, 8, [bytes(4)] * 4, bytes(1024), compression=1))
     with pytest.raises(host.HostError):
         host.read_image(str(tmp_path / "rle.bmp"))
+
+
+def test_generated_tga_files_decode_like_the_reference(tmp_path):
+    """TGA variants the reference's files do not have, through the host library and the reference's
+    Texture::Load: colour-mapped (palettes of 8, 15, 16, 24, 32 bit entries, 8 and 16 bit indices, indices past
+    the palette), 15 / 16 bit true colour, grey and grey + alpha, each raw and run-length coded with packets that
+    cross rows, top and bottom origin, an image id field - equal bytes."""
+    import struct
+    rng = np.random.default_rng(10)
+    files = []
+
+    def new():
+        files.append(str(tmp_path / f"{len(files)}.tga"))
+        return files[-1]
+
+    def packets(pixels, size):
+        """random raw and run packets over the whole pixel stream (runs repeat the packet's first pixel)"""
+        out, i, n = bytearray(), 0, len(pixels) // size
+        while i < n:
+            count = min(int(rng.integers(1, 129)), n - i)
+            if rng.integers(0, 2):
+                out += bytes((128 + count - 1,)) + pixels[i * size:(i + 1) * size]
+            else:
+                out += bytes((count - 1,)) + pixels[i * size:(i + count) * size]
+            i += count
+        return bytes(out)
+
+    def tga(w, h, type_, bpp, data, palette=b"", palette_len=0, palette_bits=0, top=False, ident=b""):
+        head = struct.pack("<BBBHHBHHHHBB", len(ident), 1 if palette_len else 0, type_, 0, palette_len, palette_bits, 0, 0, w, h, bpp, 0x20 if top else 0)
+        return head + ident + palette + data
+
+    for (w, h) in ((19, 11), (1, 1), (128, 3), (5, 40)):
+        n = w * h
+        for top in (False, True):
+            for bpp in (15, 16, 24, 32):                                    # true colour
+                size = (bpp + 7) // 8
+                px = rng.integers(0, 256, n * size).astype(np.uint8).tobytes()
+                open(new(), "wb").write(tga(w, h, 2, bpp, px, top=top, ident=b"id" if bpp == 24 else b""))
+                open(new(), "wb").write(tga(w, h, 10, bpp, packets(px, size), top=top))
+            for bpp in (8, 16):                                             # grey, grey + alpha
+                size = bpp // 8
+                px = rng.integers(0, 256, n * size).astype(np.uint8).tobytes()
+                open(new(), "wb").write(tga(w, h, 3, bpp, px, top=top))
+                open(new(), "wb").write(tga(w, h, 11, bpp, packets(px, size), top=top))
+            for palette_bits in (8, 15, 16, 24, 32):                        # colour-mapped
+                for index_bits, entries in ((8, 200), (16, 700)):
+                    palette = rng.integers(0, 256, entries * ((palette_bits + 7) // 8)).astype(np.uint8).tobytes()
+                    index = rng.integers(0, entries + 20, n).astype("<u2" if index_bits == 16 else np.uint8).tobytes()
+                    open(new(), "wb").write(tga(w, h, 1, index_bits, index, palette, entries, palette_bits, top=top))
+                    open(new(), "wb").write(tga(w, h, 9, index_bits, packets(index, index_bits // 8), palette, entries, palette_bits, top=top))
+    PIL = pytest.importorskip("PIL.Image")
+    picture = rng.integers(0, 4, (21, 30, 4)).astype(np.uint8) * 80
+    for mode in ("RGB", "RGBA", "L", "LA", "P"):
+        for kw in ({}, {"compression": "tga_rle"}):
+            PIL.fromarray(picture).convert(mode).save(new(), **kw)
+    assert len(files) > 250
+    for f in files:
+        for flip in (True, False):
+            mine, theirs = host.read_image(f, flip), ref.load_texture(f, flip=flip)
+            assert mine.shape == theirs.shape and np.array_equal(mine, theirs), (f, flip)
