@@ -208,6 +208,64 @@ def golden_converged(scenes):
     np.savez_compressed(os.path.join(HERE, "golden_converged.npz"), **out)
 
 
+def golden_images():
+    """Picture files of every kind the host library reads, with the reference's decode of each (Texture::Load for
+    8-bit texels, the Skybox::Load calls for cube map faces), and the files the reference's Image::Save writes
+    for one float picture.  File bytes are stored, so the test needs neither Pillow nor the reference."""
+    import tempfile
+    import PIL.Image
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from hdr_writer import to_rgbe, write_hdr
+    from png_writer import write_png
+    rng = np.random.default_rng(77)
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        yy, xx = np.mgrid[0:23, 0:37]
+        picture = np.stack([128 + 120 * np.sin(xx / 5.0) * np.cos(yy / 4.0), (xx * 7 + yy * 3) % 256, rng.integers(0, 256, (23, 37))], axis=-1).astype(np.uint8)
+        img = PIL.Image.fromarray(picture)
+        files = {}
+
+        def path(name):
+            files[name] = os.path.join(tmp, name)
+            return files[name]
+
+        img.save(path("baseline_420.jpg"), quality=80, subsampling=2)
+        img.save(path("baseline_422_restart.jpg"), quality=60, subsampling=1, restart_marker_blocks=2)
+        img.save(path("progressive_420.jpg"), quality=75, subsampling=2, progressive=True)
+        img.save(path("progressive_444.jpg"), quality=95, subsampling=0, progressive=True)
+        img.convert("L").save(path("grey_progressive.jpg"), quality=70, progressive=True)
+        img.save(path("deflated.png"), optimize=True)
+        img.convert("P").save(path("palette.png"))
+        write_png(path("rgba16_interlaced.png"), rng.integers(0, 1 << 16, (11, 13, 4)), 6, 16, interlace=True)
+        write_png(path("grey2_key.png"), rng.integers(0, 4, (9, 10, 1)), 0, 2, trns=(2).to_bytes(2, "big"))
+        img.save(path("rle.tga"), compression="tga_rle")
+        img.convert("P").save(path("colour_mapped.tga"))
+        img.convert("LA").save(path("grey_alpha.tga"))
+        img.convert("P").save(path("palette.bmp"))
+        img.convert("1").save(path("one_bit.bmp"))
+        img.save(path("rgb.bmp"))
+        radiance = np.exp(rng.uniform(-8, 8, (9, 20, 1))) * rng.uniform(0, 1, (9, 20, 3))
+        radiance[4:, :10] = radiance[4, 0]
+        write_hdr(path("run_length.hdr"), to_rgbe(radiance), True)
+        write_hdr(path("flat.hdr"), to_rgbe(radiance[:, :7]), False, "#?RGBE")
+        for name, f in files.items():
+            out[f"file_{name}"] = np.frombuffer(open(f, "rb").read(), np.uint8)
+            if name.endswith(".hdr"):
+                out[f"faces_{name}"] = ref.load_skybox_face(f, True)
+            else:
+                out[f"texels_{name}"] = ref.load_texture(f, True)
+                out[f"faces_{name}"] = ref.load_skybox_face(f, False)
+        shaded = np.stack([0.5 + 0.6 * np.sin(xx / 6.0 + yy / 9.0), (xx / 37.0) * (yy / 23.0), 0.3 + 0.2 * np.cos(yy / 2.0)], axis=-1)
+        shaded = (shaded + rng.normal(0, 0.03, shaded.shape)).astype(np.float32)
+        shaded[5:12, 8:30] = (0.9, 0.1, 0.1)
+        out["rendered"] = shaded
+        for ext in ("png", "tga", "bmp", "jpg"):
+            f = os.path.join(tmp, "saved." + ext)
+            ref.save_image(f, shaded)
+            out[f"saved_{ext}"] = np.frombuffer(open(f, "rb").read(), np.uint8)
+    np.savez_compressed(os.path.join(HERE, "golden_images.npz"), **out)
+
+
 def main():
     if not ref.available():
         sys.exit("oracle/_ref/libptref.so is missing: run `make ref` in the container that holds /root/reference")
@@ -215,12 +273,16 @@ def main():
     if "--only-converged" in sys.argv:   # the other files stay as they are
         golden_converged(scenes)
         return
+    if "--only-images" in sys.argv:
+        golden_images()
+        return
     for name, scene in scenes.items():
         scene.save(os.path.join(HERE, f"{name}_scene.npz"))
         golden_for(name, scene)
     golden_leaf()
     golden_bvh(scenes)
     golden_converged(scenes)
+    golden_images()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")

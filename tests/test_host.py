@@ -201,3 +201,24 @@ def test_command_line_host_usage_and_failures(tmp_path):
     import torch
     if not torch.cuda.is_available():
         assert "Could not upload the scene" in r.stdout and not (tmp_path / "k.png").exists()
+
+
+def test_picture_files_decode_and_save_like_the_committed_reference_vectors(tmp_path):
+    """tests/golden/golden_images.npz (made by tests/golden/make_golden.py from the reference's decoder and
+    writer): 17 files - baseline and progressive JPEG, PNG, TGA, BMP, Radiance HDR - with the reference's
+    texels (Texture::Load) and cube map face floats (Skybox::Load's stbi_loadf), and the four files
+    Image::Save writes for one float picture.  The host library reproduces all of them bit for bit."""
+    golden = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_images.npz"))
+    names = [k[5:] for k in golden.files if k.startswith("file_")]
+    assert len(names) == 17
+    for name in names:
+        f = tmp_path / name
+        f.write_bytes(golden["file_" + name].tobytes())
+        if not name.endswith(".hdr"):
+            assert np.array_equal(host.read_image(str(f), True), golden["texels_" + name]), name
+        faces = host.read_image_float(str(f), name.endswith(".hdr"))
+        assert faces.tobytes() == golden["faces_" + name].tobytes(), name
+    for ext in ("png", "tga", "bmp", "jpg"):
+        f = tmp_path / ("saved." + ext)
+        host.write_image(str(f), golden["rendered"])
+        assert f.read_bytes() == golden["saved_" + ext].tobytes(), ext
