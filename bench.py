@@ -104,6 +104,12 @@ def main():
     for w in range(args.warmup):
         run_step(w, False)
     warm = dev.stats()
+    if dist is not None:
+        # the collective's first use sets up RCCL's channels and buffers: do that on a scratch tensor of the
+        # film's shape, outside the timed region like the warm-up steps
+        scratch = torch.zeros_like(path_tracer.film_tensor(dev, local_rank))
+        dist.reduce(scratch, dst=0, op=dist.ReduceOp.SUM)
+        del scratch
 
     barrier()
     t_start = time.perf_counter()
