@@ -2,6 +2,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <fstream>
 
@@ -612,8 +613,26 @@ bool ReadImageRGBA8( const std::string& filename, bool flipVertically, ImageRGBA
     else if ( f.size() > 2 && f[0] == 'B' && f[1] == 'M' ) ok = ReadBmp( f, out, error );
     else if ( f.size() > 2 && f[0] == 0xFF && f[1] == 0xD8 ) ok = ReadJpegRGBA8( filename, out, error );
     else if ( f.size() > 4 && f[0] == 0x89 && f[1] == 'P' && f[2] == 'N' && f[3] == 'G' ) ok = ReadPngRGBA8( f, out, error );
+    else if ( IsRadianceFile( f ) )
+    {
+        // a Radiance picture asked for as bytes: the reference's decoder applies gamma 1 / 2.2 and rounds
+        std::vector< float > radiance;
+        ok = ReadRadianceRGBA32F( f, out.width, out.height, radiance, error );
+        if ( ok )
+        {
+            out.pixels.resize( radiance.size() );
+            const float inverseGamma = 1.0f / 2.2f, scale = 1.0f;
+            for ( size_t i = 0; i < radiance.size(); ++i )
+            {
+                float z = ( i & 3 ) == 3 ? radiance[i] * 255 + 0.5f
+                                         : static_cast< float >( std::pow( static_cast< double >( radiance[i] * scale ), static_cast< double >( inverseGamma ) ) ) * 255 + 0.5f;
+                z = z < 0 ? 0 : ( z > 255 ? 255 : z );
+                out.pixels[i] = static_cast< uint8_t >( static_cast< int >( z ) );
+            }
+        }
+    }
     else if ( ext == "tga" ) ok = ReadTga( f, out, error );
-    else error = "image format of '" + filename + "' is not decoded by this host (TGA, PNG, JPEG, BMP, PPM only)";
+    else error = "image format of '" + filename + "' is not decoded by this host (TGA, PNG, JPEG, BMP, PPM, HDR only)";
     if ( !ok )
     {
         error = "Failed to load image '" + filename + "': " + error;

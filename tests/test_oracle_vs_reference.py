@@ -406,6 +406,8 @@ def test_cube_map_face_decoding_equals_the_reference_float_load(tmp_path):
             mine, theirs = host.read_image_float(f, flip), ref.load_skybox_face(f, flip)
             assert mine.shape == theirs.shape and mine.tobytes() == theirs.tobytes(), (f, flip)
             seen_large |= bool(mine[..., :3].max() > 100)
+            # the same file asked for as a texture: gamma 1 / 2.2, times 255, rounded, clamped
+            assert np.array_equal(host.read_image(f, flip), ref.load_texture(f, flip=flip)), (f, flip)
     assert seen_large
     with open(tmp_path / "truncated.hdr", "wb") as f:
         f.write(open(files[0], "rb").read()[:90])
