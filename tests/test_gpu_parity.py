@@ -428,7 +428,10 @@ def mutated_scene(base, seed):
         n = int(rng.integers(1, 9))
         s.skybox_width = s.skybox_height = n
         sky = rng.uniform(0, 1, (6, n, n, 4)).astype(np.float32)
-        s.skybox = (np.floor(sky * 255) / np.float32(255)).astype(np.float32).reshape(-1)
+        if n % 2:   # the bytes of an 8-bit picture
+            s.skybox = (np.floor(sky * 255) / np.float32(255)).astype(np.float32).reshape(-1)
+        else:       # the floats of a Radiance picture, far above 1
+            s.skybox = (sky * np.exp(rng.uniform(-3, 5, (6, n, n, 1))).astype(np.float32)).reshape(-1)
     else:
         s.background_radiance = rng.uniform(0, 1, 3).astype(np.float32)
     return s
