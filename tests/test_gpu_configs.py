@@ -8,6 +8,8 @@ Scenes: the procedural stand-ins of pathtracer_amd/host/generators.cpp (the refe
 are not in its checkout), built by this repository's host library with the reference's SAH builder restated.
 Bars as in test_gpu_parity.py: counters equal, radiance within 1e-4 relative per pixel.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -163,3 +165,50 @@ def test_soup_20m_triangles_4k():
             lin, stats = check_against_oracle(dev, checker.OracleScene(desc), 1, 21, "soup 20M 4K 1 spp", lights=False)
             assert stats.shaded_hits > 0 and lin.mean() > 0.0
             check_split_is_bit_identical(dev, 2, 1, seed=2)
+
+
+@pytest.mark.gpu
+def test_command_line_program_from_a_scene_file(tmp_path):
+    """`pathTracer SCENE_FILE` as the reference's main runs it (src/main.cpp:11-53): scene JSON with an OBJ / MTL
+    model, a TGA texture, a sphere, three kinds of light and a cube map of Radiance faces; two entries in
+    "SamplesPerPixel", so two pictures with the "_<spp>" suffix, written into the working directory under the
+    file name's stem.  Each saved file is byte for byte what the Python mirror of PathTracer::Render / SaveImage
+    produces from the same scene, seed and sample count, and the log has the reference's lines."""
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_fuzz_host import OBJ, MTL, SCENE
+    from hdr_writer import to_rgbe, write_hdr
+    from pathtracer_amd.path_tracer import PathTracer, Scene
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rng = np.random.default_rng(12)
+    for d in ("scenes", "models", "sky", "run"):
+        os.makedirs(tmp_path / d)
+    (tmp_path / "models" / "model.obj").write_text(OBJ)
+    (tmp_path / "models" / "model.mtl").write_text(MTL)
+    checker_board = np.indices((8, 8)).sum(axis=0) % 2
+    host.write_image(str(tmp_path / "models" / "checker.tga"), np.repeat(checker_board[..., None], 3, axis=2).astype(np.float32))
+    names = ("right", "left", "top", "bottom", "back", "front")
+    for k, name in enumerate(names):
+        write_hdr(str(tmp_path / "sky" / f"{name}.hdr"), to_rgbe(rng.uniform(0, 1, (8, 8, 3)) * (0.5 + k)))
+    sky = '"Skybox": { "name": "sky", ' + ", ".join(f'"{n}": "sky/{n}.hdr"' for n in names) + " },"
+    text = SCENE.replace('"BackgroundColor": { "color": [ 0.1, 0.2, 0.3 ] },', sky).replace('"filename": "out.png"', '"filename": "pictures/out.jpg"')
+    assert "Skybox" in text and "out.jpg" in text
+    (tmp_path / "scenes" / "e2e.json").write_text(text)
+
+    exe = os.path.join(root, "pathtracer_amd", "pathTracer")
+    r = subprocess.run([exe, str(tmp_path / "scenes" / "e2e.json"), "--seed", "5"], capture_output=True, text=True, cwd=tmp_path / "run", timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    for line in ("Number of shapes: 11", "\tSpheres: 1", "\tTriangles: 10", "\tPointLight: 1", "\tDirectionalLights: 1",
+                 "Rendering scene with SPP = 2...", "Rendering scene with SPP = 4...", "Rendered scene in "):
+        assert line in r.stdout, (line, r.stdout)
+    assert sorted(os.listdir(tmp_path / "run")) == ["out_2.jpg", "out_4.jpg"]
+
+    scene = Scene.Load(str(tmp_path / "scenes" / "e2e.json"), str(tmp_path) + "/")
+    assert scene.numSamplesPerPixel == [2, 4]
+    tracer = PathTracer(seed=5)
+    for i, spp in enumerate(scene.numSamplesPerPixel):
+        tracer.Render(scene, i)
+        assert tracer.SaveImage(str(tmp_path / f"mirror_{spp}.jpg"))
+        assert (tmp_path / f"mirror_{spp}.jpg").read_bytes() == (tmp_path / "run" / f"out_{spp}.jpg").read_bytes(), spp
+        assert tracer.renderedImage.max() > 0.05
