@@ -183,3 +183,13 @@ class RefScene:
         out = np.zeros((self.height, self.width, 3), np.float32)
         _check(lib().ref_render(self._h, _p(rot), int(spp), C.c_uint64(seed), _p(out)))
         return out
+
+    def flatten(self, camera_rotation_rad):
+        """The reference-side binding (oracle/pt_flatten.hpp) on this scene's PT::Scene: a SceneData copied from
+        the PtSceneDesc that a maintainer's `Flatten( scene )` hands to pt_upload_scene."""
+        from pathtracer_amd import abi
+        from pathtracer_amd.scene import SceneData
+        rot = _f32(camera_rotation_rad)
+        desc = abi.PtSceneDesc()
+        _check(lib().ref_flatten(self._h, _p(rot), C.byref(desc)))
+        return SceneData.from_desc(desc)

@@ -36,10 +36,13 @@
 
 #include "pt_api.h"
 #include "pt_rng.h"
+#define PT_FLATTEN_NO_SKYBOX // skybox.cpp is not part of this build
+#include "pt_flatten.hpp"
 
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <string>
 #include <unistd.h>
 #include <vector>
@@ -135,6 +138,7 @@ struct RefScene
     std::map< const PT::Material*, int > materialIndex;
     PtCamera camera{};
     int width = 0, height = 0;
+    std::unique_ptr< PT::FlatScene > flat; // what ref_flatten last produced
 };
 
 static thread_local std::string g_error;
@@ -627,16 +631,10 @@ int ref_li_image( RefScene* r, int sppTotal, int s0, int s1, uint32_t rngMode, u
     return 0;
 }
 
-// Runs the reference's PathTracer::Render itself (path_tracer.cpp:158-222), single threaded so that its
-// loops visit samples in row-major, sample-minor order, and returns renderedImage: the tonemapped, gamma
-// corrected, clamped picture.  cameraRotation (radians) goes through Camera::UpdateOrientationVectors;
-// the call fails if that does not reproduce the direction vectors stored with the scene.
-int ref_render( RefScene* r, const float cameraRotation[3], int spp, uint64_t seed, float* rgbTonemapped )
+// Gives the reference's Camera the flattened scene's position and lens and `cameraRotation` (radians), lets
+// Camera::UpdateOrientationVectors derive the direction vectors and fails if they are not the stored ones.
+static int SetCamera( RefScene* r, const float cameraRotation[3] )
 {
-    if ( !r || !rgbTonemapped ) return Fail( "ref_render: null argument" );
-#ifdef _OPENMP
-    omp_set_num_threads( 1 );
-#endif
     PT::Camera& cam = r->scene.camera;
     cam.position    = V3( r->camera.position );
     cam.rotation    = V3( cameraRotation );
@@ -647,6 +645,20 @@ int ref_render( RefScene* r, const float cameraRotation[3], int spp, uint64_t se
     cam.UpdateOrientationVectors();
     if ( cam.GetViewDir() != V3( r->camera.view_dir ) || cam.GetUpDir() != V3( r->camera.up_dir ) || cam.GetRightDir() != V3( r->camera.right_dir ) )
         return Fail( "Camera::UpdateOrientationVectors disagrees with the camera vectors of the flattened scene" );
+    return 0;
+}
+
+// Runs the reference's PathTracer::Render itself (path_tracer.cpp:158-222), single threaded so that its
+// loops visit samples in row-major, sample-minor order, and returns renderedImage: the tonemapped, gamma
+// corrected, clamped picture.  cameraRotation (radians) goes through Camera::UpdateOrientationVectors;
+// the call fails if that does not reproduce the direction vectors stored with the scene.
+int ref_render( RefScene* r, const float cameraRotation[3], int spp, uint64_t seed, float* rgbTonemapped )
+{
+    if ( !r || !rgbTonemapped ) return Fail( "ref_render: null argument" );
+#ifdef _OPENMP
+    omp_set_num_threads( 1 );
+#endif
+    if ( int rc = SetCamera( r, cameraRotation ) ) return rc;
     r->scene.numSamplesPerPixel = { spp };
 
     SetRng( 0, seed, nullptr, 0, spp, 0 );
@@ -660,6 +672,25 @@ int ref_render( RefScene* r, const float cameraRotation[3], int spp, uint64_t se
     omp_set_num_threads( omp_get_num_procs() );
 #endif
     std::memcpy( rgbTonemapped, tracer.renderedImage.GetPixels(), static_cast< size_t >( r->width ) * r->height * 12 );
+    return 0;
+}
+
+// The reference-side binding (pt_flatten.hpp) on the harness's PT::Scene: PT::Scene -> PtSceneDesc.  The arrays
+// stay valid until the next ref_flatten on this scene or ref_scene_destroy.
+int ref_flatten( RefScene* r, const float cameraRotation[3], PtSceneDesc* out )
+{
+    if ( !r || !cameraRotation || !out ) return Fail( "ref_flatten: null argument" );
+    if ( int rc = SetCamera( r, cameraRotation ) ) return rc;
+    try
+    {
+        r->flat.reset( new PT::FlatScene );
+        PT::Flatten( r->scene, *r->flat );
+    }
+    catch ( const std::exception& e )
+    {
+        return Fail( e.what() );
+    }
+    *out = r->flat->desc;
     return 0;
 }
 

@@ -569,3 +569,39 @@ def test_generated_tga_files_decode_like_the_reference(tmp_path):
         for flip in (True, False):
             mine, theirs = host.read_image(f, flip), ref.load_texture(f, flip=flip)
             assert mine.shape == theirs.shape and np.array_equal(mine, theirs), (f, flip)
+
+
+@pytest.mark.parametrize("name", ["cornell", "mixed"])
+def test_reference_side_binding_flattens_a_scene_to_the_same_render(name, scenes):
+    """oracle/pt_flatten.hpp is the file a maintainer of the reference adds: PT::Scene -> PtSceneDesc.  On the
+    PT::Scene the harness builds from a fixture (meshes, spheres, textures, every kind of light), it returns the
+    BVH nodes byte for byte, the shapes in bvh.shapes order, the lights in scene order and the camera that
+    Camera::UpdateOrientationVectors derives; materials and meshes come out in order of first use, so the check
+    is what the arrays render to: the checker's radiance and counters from the flattened arrays equal those from
+    the original arrays and the reference's own Li, bit for bit."""
+    rotation = np.array([0.1, -0.3, 0.0], np.float32)
+    scene = scenes[name].with_image(20, 16, 20 / 16)
+    view, up, right = host.camera_vectors(rotation)
+    scene.camera = dict(scene.camera, view_dir=view, up_dir=up, right_dir=right)
+    desc = scene.to_desc()
+    rs = ref.RefScene(desc)
+    flat = rs.flatten(rotation)
+    assert flat.nodes.tobytes() == scene.nodes.tobytes()
+    assert np.array_equal(flat.prims["type"], scene.prims["type"])
+    assert len(flat.triangles) == len(scene.triangles) and len(flat.spheres) == len(scene.spheres)
+    assert np.array_equal(flat.lights["type"], scene.lights["type"]) and np.array_equal(flat.lights["prim"], scene.lights["prim"])
+    assert flat.lights["Lemit"].tobytes() == scene.lights["Lemit"].tobytes()
+    for k in ("position", "view_dir", "up_dir", "right_dir"):
+        assert np.array_equal(flat.camera[k], scene.camera[k]), k
+    assert (flat.image_width, flat.image_height, flat.max_depth) == (20, 16, scene.max_depth)
+    # world-space corners of every triangle, in shape order
+    def corners(s):
+        t = s.triangles[s.prims["index"][s.prims["type"] == abi.PT_PRIM_TRIANGLE]]
+        base = s.meshes["vertex_offset"][t["mesh"]]
+        return np.stack([s.vertices[base + t[i]] for i in ("i0", "i1", "i2")], axis=1)
+    assert corners(flat).tobytes() == corners(scene).tobytes()
+    want, want_stats = checker.OracleScene(desc).li_image(3, seed=2)
+    got, got_stats = checker.OracleScene(flat.to_desc()).li_image(3, seed=2)
+    theirs, _ = rs.li_image(3, seed=2)
+    assert got.tobytes() == want.tobytes() == theirs.tobytes()
+    assert got_stats == want_stats
