@@ -193,3 +193,16 @@ class RefScene:
         desc = abi.PtSceneDesc()
         _check(lib().ref_flatten(self._h, _p(rot), C.byref(desc)))
         return SceneData.from_desc(desc)
+
+    def render_gpu(self, camera_rotation_rad, spp, seed=0, save_as=None):
+        """The reference's PT::Scene / PathTracer / SaveImage with Render's body replaced by the binding of
+        oracle/pt_render_binding.hpp, on the GPU library: tonemapped image (H, W, 3).  Needs a GPU."""
+        from pathtracer_amd import api
+        gpu = api.lib()
+        entry = (C.c_void_p * 5)(*[C.cast(getattr(gpu, n), C.c_void_p) for n in
+                                    ("pt_upload_scene", "pt_render", "pt_readback", "pt_destroy_scene", "pt_last_error")])
+        rot = _f32(camera_rotation_rad)
+        out = np.zeros((self.height, self.width, 3), np.float32)
+        _check(lib().ref_render_gpu(self._h, _p(rot), int(spp), C.c_uint64(seed), entry, _p(out),
+                                    save_as.encode() if save_as else None))
+        return out

@@ -38,6 +38,8 @@
 #include "pt_rng.h"
 #define PT_FLATTEN_NO_SKYBOX // skybox.cpp is not part of this build
 #include "pt_flatten.hpp"
+#define PT_BINDING_NO_LINK // the GPU library is handed over at run time, see ref_render_gpu
+#include "pt_render_binding.hpp"
 
 #include <cstdio>
 #include <cstring>
@@ -691,6 +693,35 @@ int ref_flatten( RefScene* r, const float cameraRotation[3], PtSceneDesc* out )
         return Fail( e.what() );
     }
     *out = r->flat->desc;
+    return 0;
+}
+
+// The reference's host objects over the GPU library: PT::Scene and PT::PathTracer as the reference defines
+// them, Render's body replaced by pt_render_binding.hpp, then the reference's own SaveImage -> Image::Save when
+// `saveAs` is given.  entryPoints: pt_upload_scene, pt_render, pt_readback, pt_destroy_scene, pt_last_error of
+// an already loaded libptamd.so, in that order.  Returns renderedImage (tonemapped, W * H * 3 floats).
+int ref_render_gpu( RefScene* r, const float cameraRotation[3], int spp, uint64_t seed, void* const entryPoints[5], float* rgbTonemapped, const char* saveAs )
+{
+    if ( !r || !cameraRotation || !entryPoints || !rgbTonemapped ) return Fail( "ref_render_gpu: null argument" );
+    if ( int rc = SetCamera( r, cameraRotation ) ) return rc;
+    PT::PtApi api;
+    api.upload_scene  = reinterpret_cast< decltype( api.upload_scene ) >( entryPoints[0] );
+    api.render        = reinterpret_cast< decltype( api.render ) >( entryPoints[1] );
+    api.readback      = reinterpret_cast< decltype( api.readback ) >( entryPoints[2] );
+    api.destroy_scene = reinterpret_cast< decltype( api.destroy_scene ) >( entryPoints[3] );
+    api.last_error    = reinterpret_cast< decltype( api.last_error ) >( entryPoints[4] );
+    r->scene.numSamplesPerPixel = { spp };
+    PT::PathTracer tracer;
+    try
+    {
+        if ( !PT::RenderOnGpu( tracer, &r->scene, 0, seed, api ) ) return Fail( std::string( "RenderOnGpu failed: " ) + api.last_error() );
+    }
+    catch ( const std::exception& e )
+    {
+        return Fail( e.what() );
+    }
+    std::memcpy( rgbTonemapped, tracer.renderedImage.GetPixels(), static_cast< size_t >( r->width ) * r->height * 12 );
+    if ( saveAs && !tracer.SaveImage( saveAs ) ) return Fail( "PathTracer::SaveImage failed" );
     return 0;
 }
 

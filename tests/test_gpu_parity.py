@@ -11,7 +11,7 @@ import pytest
 
 from conftest import assert_bits_equal
 from oracle import checker
-from pathtracer_amd import abi, api
+from pathtracer_amd import abi, api, host
 
 pytestmark = pytest.mark.gpu
 
@@ -480,3 +480,34 @@ def test_tie_breaking_and_rounding_cases():
             radiance_close(lin, img / np.float32(4), what)
             assert stats.nodes_closest == ostats["nodes_closest"] and stats.tri_tests_closest == ostats["tri_tests_closest"]
             assert stats.shaded_hits == ostats["shaded_hits"] and stats.shaded_hits > 100, what
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["cornell", "mixed"])
+def test_reference_host_objects_over_the_gpu_library(name, scenes, tmp_path):
+    """The drop-in as a maintainer of the reference would build it: the reference's own PT::Scene, Camera,
+    PathTracer and Image::Save (compiled from its sources in the checking library), with the body of
+    PathTracer::Render replaced by oracle/pt_render_binding.hpp (flatten -> pt_upload_scene -> pt_render ->
+    pt_readback into renderedImage).  The picture equals, bit for bit, what the same arrays give through the
+    Python binding, its mean equals the reference's CPU Li with the same seed to 1e-4 relative, and the file
+    the reference's SaveImage writes from it is byte for byte the host library's."""
+    from oracle import ref
+    if not ref.available():
+        pytest.skip("oracle/_ref/libptref.so not built")
+    rotation = np.array([0.1, -0.3, 0.0], np.float32)
+    scene = scenes[name].with_image(40, 30, 40 / 30)
+    view, up, right = host.camera_vectors(rotation)
+    scene.camera = dict(scene.camera, view_dir=view, up_dir=up, right_dir=right)
+    desc = scene.to_desc()
+    rs = ref.RefScene(desc)
+    saved = str(tmp_path / "reference_host.png")
+    picture = rs.render_gpu(rotation, spp=5, seed=9, save_as=saved)
+    with api.DeviceScene(desc) as dev:
+        dev.render(5, seed=9)
+        linear, tonemapped, _ = dev.readback()
+    assert picture.tobytes() == tonemapped.tobytes()
+    sums, _ = rs.li_image(5, seed=9)                     # the reference's CPU Li, same Philox samples
+    radiance_close(linear, sums / np.float32(5), f"{name}: GPU under the reference's host objects vs its CPU Li")
+    host.write_image(str(tmp_path / "host.png"), tonemapped)
+    assert open(saved, "rb").read() == (tmp_path / "host.png").read_bytes()
+    assert picture.max() > 0.05
