@@ -194,7 +194,7 @@ class RefScene:
         _check(lib().ref_flatten(self._h, _p(rot), C.byref(desc)))
         return SceneData.from_desc(desc)
 
-    def render_gpu(self, camera_rotation_rad, spp, seed=0, save_as=None):
+    def render_gpu(self, camera_rotation_rad, spp, seed=0, save_as=None, tonemap_on_gpu=False):
         """The reference's PT::Scene / PathTracer / SaveImage with Render's body replaced by the binding of
         oracle/pt_render_binding.hpp, on the GPU library: tonemapped image (H, W, 3).  Needs a GPU."""
         from pathtracer_amd import api
@@ -203,6 +203,6 @@ class RefScene:
                                     ("pt_upload_scene", "pt_render", "pt_readback", "pt_destroy_scene", "pt_last_error")])
         rot = _f32(camera_rotation_rad)
         out = np.zeros((self.height, self.width, 3), np.float32)
-        _check(lib().ref_render_gpu(self._h, _p(rot), int(spp), C.c_uint64(seed), entry, _p(out),
+        _check(lib().ref_render_gpu(self._h, _p(rot), int(spp), C.c_uint64(seed), entry, int(tonemap_on_gpu), _p(out),
                                     save_as.encode() if save_as else None))
         return out

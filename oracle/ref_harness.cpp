@@ -697,10 +697,10 @@ int ref_flatten( RefScene* r, const float cameraRotation[3], PtSceneDesc* out )
 }
 
 // The reference's host objects over the GPU library: PT::Scene and PT::PathTracer as the reference defines
-// them, Render's body replaced by pt_render_binding.hpp, then the reference's own SaveImage -> Image::Save when
-// `saveAs` is given.  entryPoints: pt_upload_scene, pt_render, pt_readback, pt_destroy_scene, pt_last_error of
+// them, Render's sample loop replaced by pt_render_binding.hpp, the tonemap pass either the reference's own
+// (tonemapOnGpu = 0) or the library's, then the reference's own SaveImage -> Image::Save when `saveAs` is given.  entryPoints: pt_upload_scene, pt_render, pt_readback, pt_destroy_scene, pt_last_error of
 // an already loaded libptamd.so, in that order.  Returns renderedImage (tonemapped, W * H * 3 floats).
-int ref_render_gpu( RefScene* r, const float cameraRotation[3], int spp, uint64_t seed, void* const entryPoints[5], float* rgbTonemapped, const char* saveAs )
+int ref_render_gpu( RefScene* r, const float cameraRotation[3], int spp, uint64_t seed, void* const entryPoints[5], int tonemapOnGpu, float* rgbTonemapped, const char* saveAs )
 {
     if ( !r || !cameraRotation || !entryPoints || !rgbTonemapped ) return Fail( "ref_render_gpu: null argument" );
     if ( int rc = SetCamera( r, cameraRotation ) ) return rc;
@@ -714,11 +714,22 @@ int ref_render_gpu( RefScene* r, const float cameraRotation[3], int spp, uint64_
     PT::PathTracer tracer;
     try
     {
-        if ( !PT::RenderOnGpu( tracer, &r->scene, 0, seed, api ) ) return Fail( std::string( "RenderOnGpu failed: " ) + api.last_error() );
+        if ( !PT::RenderOnGpu( tracer, &r->scene, 0, seed, api, tonemapOnGpu != 0 ) ) return Fail( std::string( "RenderOnGpu failed: " ) + api.last_error() );
     }
     catch ( const std::exception& e )
     {
         return Fail( e.what() );
+    }
+    if ( !tonemapOnGpu ) // the pass Render ends with, src/path_tracer.cpp:211-219
+    {
+        const PT::Camera& cam = r->scene.camera;
+        tracer.renderedImage.ForAllPixels( [&]( const glm::vec3& pixel ) {
+            glm::vec3 newColor = pixel;
+            newColor           = PT::Uncharted2Tonemap( newColor, cam.exposure );
+            newColor           = PT::GammaCorrect( newColor, cam.gamma );
+            newColor           = glm::clamp( newColor, glm::vec3( 0 ), glm::vec3( 1 ) );
+            return newColor;
+        } );
     }
     std::memcpy( rgbTonemapped, tracer.renderedImage.GetPixels(), static_cast< size_t >( r->width ) * r->height * 12 );
     if ( saveAs && !tracer.SaveImage( saveAs ) ) return Fail( "PathTracer::SaveImage failed" );

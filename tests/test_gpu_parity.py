@@ -486,11 +486,12 @@ def test_tie_breaking_and_rounding_cases():
 @pytest.mark.parametrize("name", ["cornell", "mixed"])
 def test_reference_host_objects_over_the_gpu_library(name, scenes, tmp_path):
     """The drop-in as a maintainer of the reference would build it: the reference's own PT::Scene, Camera,
-    PathTracer and Image::Save (compiled from its sources in the checking library), with the body of
+    PathTracer and Image::Save (compiled from its sources in the checking library), with the sample loop of
     PathTracer::Render replaced by oracle/pt_render_binding.hpp (flatten -> pt_upload_scene -> pt_render ->
-    pt_readback into renderedImage).  The picture equals, bit for bit, what the same arrays give through the
-    Python binding, its mean equals the reference's CPU Li with the same seed to 1e-4 relative, and the file
-    the reference's SaveImage writes from it is byte for byte the host library's."""
+    pt_readback into renderedImage) and its tonemap pass kept.  The picture and the PNG file SaveImage writes
+    from it equal, bit for bit and byte for byte, those of the reference's CPU Li over the same Philox samples
+    followed by its tonemap and Image::Save.  With the tonemap done by the library instead, the picture is the
+    Python binding's to the bit and within 1e-6 of the CPU one."""
     from oracle import ref
     if not ref.available():
         pytest.skip("oracle/_ref/libptref.so not built")
@@ -502,12 +503,20 @@ def test_reference_host_objects_over_the_gpu_library(name, scenes, tmp_path):
     rs = ref.RefScene(desc)
     saved = str(tmp_path / "reference_host.png")
     picture = rs.render_gpu(rotation, spp=5, seed=9, save_as=saved)
-    with api.DeviceScene(desc) as dev:
-        dev.render(5, seed=9)
-        linear, tonemapped, _ = dev.readback()
-    assert picture.tobytes() == tonemapped.tobytes()
+
     sums, _ = rs.li_image(5, seed=9)                     # the reference's CPU Li, same Philox samples
-    radiance_close(linear, sums / np.float32(5), f"{name}: GPU under the reference's host objects vs its CPU Li")
-    host.write_image(str(tmp_path / "host.png"), tonemapped)
+    cpu_picture, _ = ref.tonemap((sums / np.float32(5)).reshape(-1, 3), float(scene.camera["exposure"]), float(scene.camera["gamma"]))
+    cpu_picture = cpu_picture.reshape(30, 40, 3)
+    assert picture.tobytes() == cpu_picture.tobytes()
+    ref.save_image(str(tmp_path / "cpu.png"), cpu_picture)
+    assert open(saved, "rb").read() == (tmp_path / "cpu.png").read_bytes()
+    host.write_image(str(tmp_path / "host.png"), picture)
     assert open(saved, "rb").read() == (tmp_path / "host.png").read_bytes()
     assert picture.max() > 0.05
+
+    on_gpu = rs.render_gpu(rotation, spp=5, seed=9, tonemap_on_gpu=True)
+    with api.DeviceScene(desc) as dev:
+        dev.render(5, seed=9)
+        _, tonemapped, _ = dev.readback()
+    assert on_gpu.tobytes() == tonemapped.tobytes()
+    assert np.abs(on_gpu - cpu_picture).max() <= 1e-6
