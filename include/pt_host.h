@@ -71,6 +71,12 @@ int pth_sphere_world_to_local( const float position[3], const float rotation[3],
  * .png / .tga / .bmp / .jpg / .jpeg as the reference's writer does, byte for byte, or .ppm. */
 int pth_write_image( const char* filename, const float* rgb, int32_t width, int32_t height );
 
+/* The tonemap pass PathTracer::Render ends with (src/path_tracer.cpp:211-219), in place on num_pixels * 3 floats of
+ * linear radiance: op 0 = Uncharted2, 1 = Reinhard; then pow( x, 1 / gamma ) and clamp.  Uses the C library's powf
+ * as the reference does, so the result is the reference's bit for bit (pt_readback's tonemap on the device is
+ * within one unit in the last place of it). */
+int pth_tonemap( float* rgb, uint64_t num_pixels, float exposure, float gamma, int32_t op );
+
 /* Texture::Load's decode (src/resource/texture.cpp:19-33: stbi_load with four channels, rows flipped when asked):
  * RGBA8, row 0 first.  Call with rgba = NULL to get the size.  TGA, PNG, baseline and progressive JPEG, BMP, PPM / PGM. */
 int pth_read_image( const char* filename, int32_t flip_vertically, int32_t* width, int32_t* height, uint8_t* rgba, uint64_t capacity );

@@ -38,6 +38,7 @@ def lib():
         L.pth_sphere_world_to_local.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
         L.pth_write_image.argtypes = [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32]
         L.pth_read_image.argtypes = [C.c_char_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_void_p, C.c_uint64]
+        L.pth_tonemap.argtypes = [C.c_void_p, C.c_uint64, C.c_float, C.c_float, C.c_int32]
         L.pth_read_image_float.argtypes = [C.c_char_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_void_p, C.c_uint64]
         L.pth_last_error.restype = C.c_char_p
         _LIB = L
@@ -156,6 +157,14 @@ def read_image(filename, flip=True):
     px = np.zeros((h.value, w.value, 4), np.uint8)
     _check(lib().pth_read_image(filename.encode(), int(flip), C.byref(w), C.byref(h), px.ctypes.data, px.nbytes))
     return px
+
+
+def tonemap(rgb, exposure, gamma, op=0):
+    """The reference's tonemap pass (src/path_tracer.cpp:211-219) on the host: Uncharted2 (op 0) or Reinhard (1),
+    gamma, clamp - with the C library's powf, hence the reference's picture bit for bit."""
+    out = np.array(rgb, np.float32, order="C")
+    _check(lib().pth_tonemap(out.ctypes.data, C.c_uint64(out.size // 3), C.c_float(exposure), C.c_float(gamma), int(op)))
+    return out
 
 
 def read_image_float(filename, flip=True):

@@ -202,6 +202,15 @@ int pth_write_image( const char* filename, const float* rgb, int32_t width, int3
     } );
 }
 
+int pth_tonemap( float* rgb, uint64_t num_pixels, float exposure, float gamma, int32_t op )
+{
+    if ( !rgb || ( op != 0 && op != 1 ) ) return Fail( "pth_tonemap: bad argument" );
+    return Guard( [&] {
+        pth::TonemapRGB( rgb, static_cast< size_t >( num_pixels ) * 3, exposure, gamma, op );
+        return 0;
+    } );
+}
+
 int pth_read_image( const char* filename, int32_t flip_vertically, int32_t* width, int32_t* height, uint8_t* rgba, uint64_t capacity )
 {
     if ( !filename || !width || !height ) return Fail( "pth_read_image: bad argument" );

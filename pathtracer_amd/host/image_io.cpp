@@ -681,6 +681,35 @@ bool ReadImageRGBA32F( const std::string& filename, bool flipVertically, int& wi
     return true;
 }
 
+namespace
+{
+    // Uncharted2TonemapHelper, src/tonemap.cpp:36-45
+    float FilmicCurve( float x )
+    {
+        const float A = 0.15f, B = 0.50f, C = 0.10f, D = 0.20f, E = 0.02f, F = 0.30f;
+        return ( ( x * ( A * x + C * B ) + D * E ) / ( x * ( A * x + B ) + D * F ) ) - E / F;
+    }
+} // namespace
+
+void TonemapRGB( float* rgb, size_t count, float exposure, float gamma, int op )
+{
+    const float whiteScale = 1.0f / FilmicCurve( 11.2f ), inverseGamma = 1.0f / gamma;
+    for ( size_t i = 0; i < count; ++i )
+    {
+        float x = rgb[i];
+        if ( op == 0 )
+            x = FilmicCurve( exposure * x ) * whiteScale;
+        else
+        {
+            const float adjusted = exposure * x;
+            x                    = adjusted / ( 1.0f + adjusted );
+        }
+        x      = std::pow( x, inverseGamma ); // float overload: the C library's powf, as glm::pow calls it
+        x      = x < 0.0f ? 0.0f : x;         // glm::clamp = min( max( x, 0 ), 1 )
+        rgb[i] = 1.0f < x ? 1.0f : x;
+    }
+}
+
 std::vector< uint8_t > QuantizeRGB8( const float* rgb, int width, int height )
 {
     std::vector< uint8_t > out( static_cast< size_t >( width ) * height * 3 );

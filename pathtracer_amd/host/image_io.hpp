@@ -34,6 +34,12 @@ bool ReadJpegRGBA8( const std::string& filename, ImageRGBA8& out, std::string& e
 // PNG of any colour type, bit depth and interlacing, converted to 8-bit RGBA the way the reference's decoder does.
 bool ReadPngRGBA8( const std::vector< uint8_t >& file, ImageRGBA8& out, std::string& error );
 
+// The pass PathTracer::Render ends with (src/path_tracer.cpp:211-219, src/tonemap.cpp:6-9, 29-53), in place, on
+// `count` floats: Uncharted2 (op 0) or Reinhard (op 1) at `exposure`, pow( x, 1 / gamma ) with the C library's powf,
+// clamp to [0, 1].  Bit for bit the reference's result on the same machine; the device's tonemap kernel
+// differs from it by one unit in the last place where powf is not correctly rounded.
+void TonemapRGB( float* rgb, size_t count, float exposure, float gamma, int op );
+
 // The reference's quantiser (src/image.cpp:57-68): 255 * clamp(c, 0, 1) truncated to uint8.
 std::vector< uint8_t > QuantizeRGB8( const float* rgb, int width, int height );
 

@@ -30,7 +30,7 @@ struct Options
     std::string sceneFile, resourceDir, output, generate;
     int width = 0, height = 0, depth = -1, spp = 0, device = 0, triangles = 0;
     uint64_t seed = 0;
-    bool haveSeed = false, stats = false;
+    bool haveSeed = false, stats = false, hostTonemap = false;
 };
 
 void Usage() { std::cout << "Usage: pathTracer SCENE_FILE" << std::endl; }
@@ -48,7 +48,9 @@ void Help()
                  "  --device N           GPU index\n"
                  "  --output FILE        override OutputImageFilename\n"
                  "  --generate atrium|knot|soup [--triangles N]   procedural scene instead of SCENE_FILE\n"
-                 "  --stats              print ray and traversal counters after each render\n";
+                 "  --stats              print ray and traversal counters after each render\n"
+                 "  --host-tonemap       run the tonemap pass on the host with the C library's powf, as the reference\n"
+                 "                       does (the saved picture is then the CPU path's to the last bit for equal samples)\n";
 }
 
 bool ParseArgs( int argc, char** argv, Options& o )
@@ -83,6 +85,8 @@ bool ParseArgs( int argc, char** argv, Options& o )
             o.output = v;
         else if ( a == "--generate" && ( v = value() ) )
             o.generate = v;
+        else if ( a == "--host-tonemap" )
+            o.hostTonemap = true;
         else if ( a == "--seed" && ( v = value() ) )
         {
             o.seed     = std::strtoull( v, nullptr, 0 );
@@ -108,7 +112,10 @@ std::string DefaultResourceDir( const std::string& sceneFile )
 class PathTracer
 {
 public:
-    PathTracer( PtScene* gpuScene, int width, int height ) : m_scene( gpuScene ), m_width( width ), m_height( height ) {}
+    PathTracer( PtScene* gpuScene, int width, int height, const PtCamera& camera, bool hostTonemap )
+        : m_scene( gpuScene ), m_width( width ), m_height( height ), m_camera( camera ), m_hostTonemap( hostTonemap )
+    {
+    }
 
     bool Render( int samplesPerPixel, uint64_t seed, PtStats* stats )
     {
@@ -124,7 +131,13 @@ public:
         params.seed         = seed;
         if ( pt_render( m_scene, &params ) != PT_OK ) return false;
         // the image holds the tonemapped picture, like Image::m_pixels after src/path_tracer.cpp:211-219
-        if ( pt_readback( m_scene, PT_TONEMAP_UNCHARTED2, nullptr, renderedImage.data(), stats ) != PT_OK ) return false;
+        if ( m_hostTonemap )
+        {
+            if ( pt_readback( m_scene, PT_TONEMAP_UNCHARTED2, renderedImage.data(), nullptr, stats ) != PT_OK ) return false;
+            if ( pth_tonemap( renderedImage.data(), static_cast< uint64_t >( m_width ) * m_height, m_camera.exposure, m_camera.gamma, 0 ) != 0 ) return false;
+        }
+        else if ( pt_readback( m_scene, PT_TONEMAP_UNCHARTED2, nullptr, renderedImage.data(), stats ) != PT_OK )
+            return false;
         const double seconds = std::chrono::duration< double >( std::chrono::steady_clock::now() - timeStart ).count();
         std::cout << "\nRendered scene in " << seconds << " seconds" << std::endl;
         return true;
@@ -137,6 +150,8 @@ public:
 private:
     PtScene* m_scene;
     int m_width, m_height;
+    PtCamera m_camera;
+    bool m_hostTonemap;
 };
 
 } // namespace
@@ -213,7 +228,7 @@ int main( int argc, char** argv )
     // Perform all the renderings ("SamplesPerPixel": [ 8, 32, ... ]), src/main.cpp:30-49
     for ( size_t it = 0; it < sppList.size(); ++it )
     {
-        PathTracer pathTracer( gpuScene, desc.image_width, desc.image_height );
+        PathTracer pathTracer( gpuScene, desc.image_width, desc.image_height, desc.camera, opt.hostTonemap );
         PtStats stats{};
         const uint64_t seed = opt.haveSeed ? opt.seed : ( static_cast< uint64_t >( entropy() ) << 32 | entropy() );
         if ( !pathTracer.Render( sppList[it], seed, &stats ) )

@@ -212,3 +212,12 @@ def test_command_line_program_from_a_scene_file(tmp_path):
         assert tracer.SaveImage(str(tmp_path / f"mirror_{spp}.jpg"))
         assert (tmp_path / f"mirror_{spp}.jpg").read_bytes() == (tmp_path / "run" / f"out_{spp}.jpg").read_bytes(), spp
         assert tracer.renderedImage.max() > 0.05
+
+    # --host-tonemap: the reference's own tonemap arithmetic (the C library's powf) on the linear radiance
+    os.makedirs(tmp_path / "run2")
+    r = subprocess.run([exe, str(tmp_path / "scenes" / "e2e.json"), "--seed", "5", "--host-tonemap", "--spp", "4", "--output", "exact.png"],
+                       capture_output=True, text=True, cwd=tmp_path / "run2", timeout=120)
+    assert r.returncode == 0 and os.listdir(tmp_path / "run2") == ["exact.png"], r.stdout + r.stderr
+    camera = scene._desc.camera
+    host.write_image(str(tmp_path / "mirror_exact.png"), host.tonemap(tracer.linearImage, camera.exposure, camera.gamma, 0))
+    assert (tmp_path / "mirror_exact.png").read_bytes() == (tmp_path / "run2" / "exact.png").read_bytes()
