@@ -140,6 +140,26 @@ def test_knot_4k_primary_and_shadow_only():
             assert stats.rays_shadow <= stats.shaded_hits
 
 
+def test_more_than_2_to_the_32_samples_in_one_render():
+    """3840x2160 at 600 samples per pixel (4.98e9 samples, past 32-bit counters and indices) in one pt_render
+    call, depth 1 on the knot: every sample is rendered once, the two halves of the sample range rendered
+    separately give the same film bit for bit, and the mean agrees with a 16 spp render of the same seed."""
+    with host.HostScene.knot(seed=2, triangles=871414) as hs:
+        hs.set_image(3840, 2160, 3840 / 2160)
+        hs.set_max_depth(1)
+        with api.DeviceScene(hs.desc()) as dev:
+            dev.render(600, seed=3)
+            whole, _, stats = dev.readback()
+            assert stats.samples == 3840 * 2160 * 600 > 2 ** 32 and stats.rays_closest == stats.samples
+            dev.render(600, 0, 300, seed=3)
+            dev.render(600, 300, 600, seed=3, accumulate=True)
+            halves, _, _ = dev.readback()
+            assert_bits_equal(halves, whole, "600 spp in one call vs two halves")
+            dev.render(16, seed=3)
+            few, _, _ = dev.readback()
+            assert np.isfinite(whole).all() and abs(float(few.mean()) - float(whole.mean())) <= 1e-3 * float(whole.mean())
+
+
 def test_soup_with_environment_map():
     """Random triangle soup under an LDR cube map (the divergence stress configuration, scaled to 2 M triangles
     so that the checker's side stays short): misses read the cube map, hits bounce up to depth 5."""
