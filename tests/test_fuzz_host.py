@@ -102,7 +102,12 @@ def test_image_readers_survive_damaged_files(fuzzer, tmp_path):
         img.convert("P").save(str(tmp_path / "palette.png"))
         img.save(str(tmp_path / "progressive.jpg"), quality=70, progressive=True)
         img.save(str(tmp_path / "progressive_restart.jpg"), quality=30, progressive=True, subsampling=0, restart_marker_blocks=2)
-        files += [str(tmp_path / n) for n in ("rle.tga", "picture.jpg", "restart.jpg", "deflated.png", "palette.png", "progressive.jpg", "progressive_restart.jpg")]
+        img.convert("P").save(str(tmp_path / "palette.bmp"))
+        img.convert("1").save(str(tmp_path / "one_bit.bmp"))
+        img.convert("P").save(str(tmp_path / "colour_mapped.tga"), compression="tga_rle")
+        img.convert("LA").save(str(tmp_path / "grey_alpha.tga"))
+        files += [str(tmp_path / n) for n in ("rle.tga", "picture.jpg", "restart.jpg", "deflated.png", "palette.png", "progressive.jpg", "progressive_restart.jpg",
+                                              "palette.bmp", "one_bit.bmp", "colour_mapped.tga", "grey_alpha.tga")]
     except ImportError:
         pass
     for f in files:
