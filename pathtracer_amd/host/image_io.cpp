@@ -177,7 +177,7 @@ namespace
         const int channels = f[1] == '6' ? 3 : 1;
         const int w = nextInt(), h = nextInt(), maxv = nextInt();
         ++pos;
-        if ( w <= 0 || h <= 0 || maxv != 255 || pos + static_cast< size_t >( w ) * h * channels > f.size() )
+        if ( w <= 0 || h <= 0 || maxv > 255 || pos + static_cast< size_t >( w ) * h * channels > f.size() ) // samples are taken as stored, whatever the maximum says
         {
             error = "unsupported or truncated PNM";
             return false;

@@ -616,3 +616,20 @@ def test_reference_side_binding_flattens_a_scene_to_the_same_render(name, scenes
     theirs, _ = rs.li_image(3, seed=2)
     assert got.tobytes() == want.tobytes() == theirs.tobytes()
     assert got_stats == want_stats
+
+
+def test_pnm_decoding_equals_the_reference_texture_load(tmp_path):
+    """Binary PGM / PPM through the host library and the reference's Texture::Load: comments in the header, a
+    maximum below 255 (samples are taken as stored), odd sizes."""
+    rng = np.random.default_rng(13)
+    files = []
+    for n, (w, h) in enumerate(((7, 5), (1, 1), (32, 3))):
+        for magic, channels in ((b"P5", 1), (b"P6", 3)):
+            for maxv, comment in ((255, b""), (100, b"# made by a test\n"), (255, b"# one\n# two\n")):
+                files.append(str(tmp_path / f"{n}_{magic.decode()}_{maxv}_{len(comment)}.pnm"))
+                body = rng.integers(0, maxv + 1, w * h * channels).astype(np.uint8).tobytes()
+                open(files[-1], "wb").write(magic + b"\n" + comment + f"{w} {h}\n{maxv}\n".encode() + body)
+    for f in files:
+        for flip in (True, False):
+            mine, theirs = host.read_image(f, flip), ref.load_texture(f, flip=flip)
+            assert mine.shape == theirs.shape and np.array_equal(mine, theirs), (f, flip)
