@@ -1,4 +1,4 @@
-// Baseline and progressive JPEG (Huffman-coded DCT, 8 bit) to RGBA8, for the textures and cube maps the reference's scenes
+// Baseline and progressive JPEG (Huffman-coded DCT, 8 bit; grey, YCbCr / RGB, Adobe CMYK / YCCK) to RGBA8, for the textures and cube maps the reference's scenes
 // name (resources/images/*.jpg).  The reference decodes them with stb_image 2.25 (Texture::Load,
 // src/resource/texture.cpp:19-33; Skybox::Load, src/resource/skybox.cpp:30-58), and a texel only equals the
 // reference's if three choices the JPEG standard leaves open are made the same way:
@@ -260,7 +260,7 @@ namespace
             m_width  = Word();
             const int n = Byte();
             if ( m_width <= 0 || m_height <= 0 ) return Fail( error, "empty picture" );
-            if ( n != 1 && n != 3 ) return Fail( error, "1 or 3 components expected" );
+            if ( n != 1 && n != 3 && n != 4 ) return Fail( error, "1, 3 or 4 components expected" );
             m_components.assign( n, Component() );
             for ( Component& c : m_components )
             {
@@ -699,7 +699,9 @@ namespace
                 r.line0 = r.line1 = c.plane.data();
                 r.buffer.assign( static_cast< size_t >( m_width ) + 3 * 4 + 8, 0 );
             }
-            const uint8_t* rows[3] = { nullptr, nullptr, nullptr };
+            const uint8_t* rows[4] = { nullptr, nullptr, nullptr, nullptr };
+            // a * b / 255, rounded, for bytes
+            auto scale = []( int a, int b ) { const unsigned t = static_cast< unsigned >( a * b + 128 ); return static_cast< uint8_t >( ( t + ( t >> 8 ) ) >> 8 ); };
             for ( int y = 0; y < m_height; ++y )
             {
                 for ( size_t k = 0; k < n; ++k )
@@ -724,6 +726,14 @@ namespace
                         o[1] = rows[1][x];
                         o[2] = rows[2][x];
                     }
+                else if ( n == 4 && m_adobeTransform == 0 ) // CMYK as Adobe writes it (inverted): ink times black
+                    for ( int x = 0; x < m_width; ++x, o += 4 )
+                    {
+                        const int black = rows[3][x];
+                        o[0] = scale( rows[0][x], black );
+                        o[1] = scale( rows[1][x], black );
+                        o[2] = scale( rows[2][x], black );
+                    }
                 else
                     for ( int x = 0; x < m_width; ++x, o += 4 )
                     {
@@ -736,6 +746,13 @@ namespace
                         o[0] = Clamp8( r >> 20 );
                         o[1] = Clamp8( g >> 20 );
                         o[2] = Clamp8( b >> 20 );
+                        if ( n == 4 && m_adobeTransform == 2 ) // YCCK: the colour is inverted, then scaled by black
+                        {
+                            const int black = rows[3][x];
+                            o[0] = scale( 255 - o[0], black );
+                            o[1] = scale( 255 - o[1], black );
+                            o[2] = scale( 255 - o[2], black );
+                        } // four components without that marker: the fourth is ignored
                     }
             }
         }

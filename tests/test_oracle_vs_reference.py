@@ -216,7 +216,8 @@ def test_jpeg_decoding_equals_the_reference_texture_load(tmp_path):
     """Baseline JPEG through the host library and through the reference's Texture::Load (stb_image): the seven
     files the reference ships (4:2:0) and generated ones - 4:4:4, 4:2:2, 4:2:0, grey, odd sizes down to 1 x 1,
     qualities 5 to 100, optimised Huffman tables, restart markers, and each of those as a progressive file (DC
-    and AC scans with successive approximation, as libjpeg's standard script orders them) - equal bytes."""
+    and AC scans with successive approximation, as libjpeg's standard script orders them), and four-component
+    files (Adobe CMYK, YCCK, unmarked) - equal bytes."""
     import glob
     files = sorted(glob.glob("/root/reference/resources/**/*.jpg", recursive=True))
     assert len(files) >= 7
@@ -246,6 +247,21 @@ def test_jpeg_decoding_equals_the_reference_texture_load(tmp_path):
             n += 1
             img.convert("L").save(f, "JPEG", quality=80, progressive=True)
             files.append(f)
+    # four components: CMYK as Adobe writes it, and the same data declared YCCK / YCbCr + unknown by the marker
+    cmyk = PIL.fromarray(np.clip(np.dstack([pictures["smooth"], pictures["noise"][..., :1]]), 0, 255).astype(np.uint8), "CMYK")
+    for subsampling in (0, 1, 2):
+        for extra in ({}, {"progressive": True}):
+            f = str(tmp_path / f"k{n}.jpg")
+            n += 1
+            cmyk.save(f, "JPEG", quality=85, subsampling=subsampling, **extra)
+            files.append(f)
+            data = bytearray(open(f, "rb").read())
+            at = data.find(b"Adobe") + 11
+            assert data[at] == 0
+            for transform in (1, 2):
+                data[at] = transform
+                files.append(str(tmp_path / f"k{n}_{transform}.jpg"))
+                open(files[-1], "wb").write(bytes(data))
     for f in files:
         for flip in (True, False):
             mine, theirs = host.read_image(f, flip), ref.load_texture(f, flip=flip)
