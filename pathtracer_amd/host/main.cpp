@@ -6,7 +6,7 @@
 //
 // Everything beyond the positional argument is optional and absent from the reference, whose settings all come
 // from the scene file: a resource directory (the reference compiles RESOURCE_DIR in), image size / depth / spp
-// overrides for the benchmark configurations, the seed (the reference is unseeded), the GPU to use, and the
+// overrides for the benchmark configurations, the seed (the reference is unseeded), the GPU or GPUs to use, and the
 // procedural scenes that stand in for assets the reference does not ship.
 #include "pt_host.h"
 
@@ -18,6 +18,8 @@
 #include <iostream>
 #include <random>
 #include <string>
+#include <algorithm>
+#include <thread>
 #include <vector>
 
 namespace fs = std::filesystem;
@@ -31,6 +33,7 @@ struct Options
     int width = 0, height = 0, depth = -1, spp = 0, device = 0, triangles = 0;
     uint64_t seed = 0;
     bool haveSeed = false, stats = false, hostTonemap = false;
+    std::vector< int > devices; // --devices: the GPUs that share a render; empty = the one of --device
 };
 
 void Usage() { std::cout << "Usage: pathTracer SCENE_FILE" << std::endl; }
@@ -46,6 +49,8 @@ void Help()
                  "  --spp N              render once with N samples per pixel instead of the scene's list\n"
                  "  --seed S             seed of the counter-based generator (default: std::random_device)\n"
                  "  --device N           GPU index\n"
+                 "  --devices A,B,...    several GPUs share every render: the scene is uploaded to each, the samples of\n"
+                 "                       every pixel are split between them and the films are summed on the first\n"
                  "  --output FILE        override OutputImageFilename\n"
                  "  --generate atrium|knot|soup [--triangles N]   procedural scene instead of SCENE_FILE\n"
                  "  --stats              print ray and traversal counters after each render\n"
@@ -79,6 +84,20 @@ bool ParseArgs( int argc, char** argv, Options& o )
             o.spp = std::atoi( v );
         else if ( a == "--device" && ( v = value() ) )
             o.device = std::atoi( v );
+        else if ( a == "--devices" && ( v = value() ) )
+        {
+            o.devices.clear();
+            for ( const char* p = v; *p; )
+            {
+                char* end = nullptr;
+                const long d = std::strtol( p, &end, 10 );
+                if ( end == p || d < 0 ) return false;
+                o.devices.push_back( static_cast< int >( d ) );
+                p = *end == ',' ? end + 1 : end;
+                if ( *end != ',' && *end != 0 ) return false;
+            }
+            if ( o.devices.empty() ) return false;
+        }
         else if ( a == "--triangles" && ( v = value() ) )
             o.triangles = std::atoi( v );
         else if ( a == "--output" && ( v = value() ) )
@@ -108,12 +127,17 @@ std::string DefaultResourceDir( const std::string& sceneFile )
     return dir.string() + "/";
 }
 
-// PathTracer of src/path_tracer.hpp:9-19 on the C-ABI: Render fills renderedImage, SaveImage writes it.
+// PathTracer of src/path_tracer.hpp:9-19 on the C-ABI: Render fills renderedImage, SaveImage writes it.  With
+// several GPUs (one uploaded copy of the scene each) every GPU renders a contiguous share of the samples of every
+// pixel from its own host thread - the shares differ by at most one sample, earlier GPUs take the larger ones -
+// and the films (sums per pixel) are added in GPU order on the host and put back on the first GPU, which
+// tonemaps.  The Philox streams are keyed by the absolute sample index, so the picture does not depend on the
+// number of GPUs beyond the order of the float additions.
 class PathTracer
 {
 public:
-    PathTracer( PtScene* gpuScene, int width, int height, const PtCamera& camera, bool hostTonemap )
-        : m_scene( gpuScene ), m_width( width ), m_height( height ), m_camera( camera ), m_hostTonemap( hostTonemap )
+    PathTracer( const std::vector< PtScene* >& gpuScenes, int width, int height, const PtCamera& camera, bool hostTonemap )
+        : m_scenes( gpuScenes ), m_width( width ), m_height( height ), m_camera( camera ), m_hostTonemap( hostTonemap )
     {
     }
 
@@ -122,22 +146,59 @@ public:
         std::cout << "\nRendering scene with SPP = " << samplesPerPixel << "..." << std::endl;
         const auto timeStart = std::chrono::steady_clock::now();
         renderedImage.assign( static_cast< size_t >( m_width ) * m_height * 3, 0.0f );
-        PtRenderParams params{};
-        params.struct_size  = sizeof( params );
-        params.spp_total    = samplesPerPixel;
-        params.sample_begin = 0;
-        params.sample_end   = samplesPerPixel;
-        params.rng_mode     = PT_RNG_PHILOX;
-        params.seed         = seed;
-        if ( pt_render( m_scene, &params ) != PT_OK ) return false;
+        const int gpus = static_cast< int >( m_scenes.size() );
+        std::vector< std::string > errors( gpus );
+        std::vector< std::thread > workers;
+        for ( int g = 0; g < gpus; ++g )
+        {
+            const int base = samplesPerPixel / gpus, extra = samplesPerPixel % gpus;
+            PtRenderParams params{};
+            params.struct_size  = sizeof( params );
+            params.spp_total    = samplesPerPixel;
+            params.sample_begin = g * base + std::min( g, extra );
+            params.sample_end   = params.sample_begin + base + ( g < extra ? 1 : 0 );
+            params.rng_mode     = PT_RNG_PHILOX;
+            params.seed         = seed;
+            auto work = [this, g, params, &errors] {
+                if ( pt_render( m_scenes[g], &params ) != PT_OK ) errors[g] = pt_last_error(); // the message is per thread
+            };
+            if ( gpus == 1 ) work();
+            else workers.emplace_back( work );
+        }
+        for ( std::thread& t : workers ) t.join();
+        for ( int g = 0; g < gpus; ++g )
+            if ( !errors[g].empty() )
+            {
+                std::cout << "GPU " << g << ": " << errors[g] << std::endl;
+                return false;
+            }
+        PtStats total{};
+        if ( gpus > 1 )
+        {
+            const size_t floats = static_cast< size_t >( m_width ) * m_height * 4;
+            std::vector< float > sum( floats ), film( floats );
+            if ( pt_download_film( m_scenes[0], sum.data() ) != PT_OK ) return false;
+            for ( int g = 1; g < gpus; ++g )
+            {
+                if ( pt_download_film( m_scenes[g], film.data() ) != PT_OK ) return false;
+                for ( size_t i = 0; i < floats; ++i ) sum[i] += film[i];
+                PtStats one{};
+                if ( pt_readback( m_scenes[g], PT_TONEMAP_NONE, nullptr, nullptr, &one ) != PT_OK ) return false;
+                Add( total, one );
+            }
+            if ( pt_upload_film( m_scenes[0], sum.data() ) != PT_OK ) return false;
+        }
         // the image holds the tonemapped picture, like Image::m_pixels after src/path_tracer.cpp:211-219
+        PtStats first{};
         if ( m_hostTonemap )
         {
-            if ( pt_readback( m_scene, PT_TONEMAP_UNCHARTED2, renderedImage.data(), nullptr, stats ) != PT_OK ) return false;
+            if ( pt_readback( m_scenes[0], PT_TONEMAP_UNCHARTED2, renderedImage.data(), nullptr, &first ) != PT_OK ) return false;
             if ( pth_tonemap( renderedImage.data(), static_cast< uint64_t >( m_width ) * m_height, m_camera.exposure, m_camera.gamma, 0 ) != 0 ) return false;
         }
-        else if ( pt_readback( m_scene, PT_TONEMAP_UNCHARTED2, nullptr, renderedImage.data(), stats ) != PT_OK )
+        else if ( pt_readback( m_scenes[0], PT_TONEMAP_UNCHARTED2, nullptr, renderedImage.data(), &first ) != PT_OK )
             return false;
+        Add( total, first );
+        if ( stats ) *stats = total;
         const double seconds = std::chrono::duration< double >( std::chrono::steady_clock::now() - timeStart ).count();
         std::cout << "\nRendered scene in " << seconds << " seconds" << std::endl;
         return true;
@@ -148,7 +209,18 @@ public:
     std::vector< float > renderedImage;
 
 private:
-    PtScene* m_scene;
+    // counters add up over the GPUs; the GPUs run side by side, so the time is the longest of theirs
+    static void Add( PtStats& sum, const PtStats& one )
+    {
+        sum.samples += one.samples;
+        sum.rays_closest += one.rays_closest;
+        sum.rays_shadow += one.rays_shadow;
+        sum.nodes_closest += one.nodes_closest;
+        sum.nodes_shadow += one.nodes_shadow;
+        sum.render_ms = std::max( sum.render_ms, one.render_ms );
+    }
+
+    std::vector< PtScene* > m_scenes;
     int m_width, m_height;
     PtCamera m_camera;
     bool m_hostTonemap;
@@ -213,11 +285,20 @@ int main( int argc, char** argv )
                   << "Number of lights: " << desc.num_lights << "\n\tAreaLight: " << numArea << "\n\tPointLight: " << numPoint
                   << "\n\tDirectionalLights: " << numDirectional << std::endl;
     }
-    PtScene* gpuScene = nullptr;
-    if ( pt_upload_scene( &desc, &gpuScene ) != PT_OK )
+    if ( opt.devices.empty() ) opt.devices.assign( 1, opt.device );
+    std::vector< PtScene* > gpuScenes;
+    for ( int device : opt.devices )
     {
-        std::cout << "Could not upload the scene: " << pt_last_error() << std::endl;
-        return 0;
+        PtSceneDesc copy = desc;
+        copy.device      = device;
+        PtScene* gpuScene = nullptr;
+        if ( pt_upload_scene( &copy, &gpuScene ) != PT_OK )
+        {
+            std::cout << "Could not upload the scene: " << pt_last_error() << std::endl;
+            for ( PtScene* uploaded : gpuScenes ) pt_destroy_scene( uploaded );
+            return 0;
+        }
+        gpuScenes.push_back( gpuScene );
     }
 
     std::vector< int > sppList( info.spp, info.spp + info.num_spp );
@@ -228,7 +309,7 @@ int main( int argc, char** argv )
     // Perform all the renderings ("SamplesPerPixel": [ 8, 32, ... ]), src/main.cpp:30-49
     for ( size_t it = 0; it < sppList.size(); ++it )
     {
-        PathTracer pathTracer( gpuScene, desc.image_width, desc.image_height, desc.camera, opt.hostTonemap );
+        PathTracer pathTracer( gpuScenes, desc.image_width, desc.image_height, desc.camera, opt.hostTonemap );
         PtStats stats{};
         const uint64_t seed = opt.haveSeed ? opt.seed : ( static_cast< uint64_t >( entropy() ) << 32 | entropy() );
         if ( !pathTracer.Render( sppList[it], seed, &stats ) )
@@ -254,7 +335,7 @@ int main( int argc, char** argv )
         if ( !pathTracer.SaveImage( filename ) ) std::cout << "Could not save image '" << filename << "'" << std::endl;
     }
 
-    pt_destroy_scene( gpuScene );
+    for ( PtScene* gpuScene : gpuScenes ) pt_destroy_scene( gpuScene );
     pth_scene_free( scene );
     return 0;
 }

@@ -233,6 +233,15 @@ def test_command_line_program_from_a_scene_file(tmp_path):
         assert (tmp_path / f"mirror_{spp}.jpg").read_bytes() == (tmp_path / "run" / f"out_{spp}.jpg").read_bytes(), spp
         assert tracer.renderedImage.max() > 0.05
 
+    # --devices: three copies of the scene (here all on GPU 0) share the samples 2 + 2 + 1; the films are summed
+    os.makedirs(tmp_path / "run3")
+    for name, extra in (("single.png", []), ("shared.png", ["--devices", "0,0,0"])):
+        r = subprocess.run([exe, str(tmp_path / "scenes" / "e2e.json"), "--seed", "5", "--spp", "5", "--stats", "--output", name] + extra,
+                           capture_output=True, text=True, cwd=tmp_path / "run3", timeout=120)
+        assert r.returncode == 0 and f"samples {32 * 24 * 5}," in r.stdout, r.stdout + r.stderr
+    single, shared = (host.read_image(str(tmp_path / "run3" / n), False).astype(int) for n in ("single.png", "shared.png"))
+    assert np.abs(single - shared).max() <= 1 and single.max() > 20      # the same samples, added in another order
+
     # --host-tonemap: the reference's own tonemap arithmetic (the C library's powf) on the linear radiance
     os.makedirs(tmp_path / "run2")
     r = subprocess.run([exe, str(tmp_path / "scenes" / "e2e.json"), "--seed", "5", "--host-tonemap", "--spp", "4", "--output", "exact.png"],
