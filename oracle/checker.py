@@ -16,7 +16,7 @@ _LIB = None
 class PtoStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         "samples", "rays_closest", "rays_shadow", "nodes_closest", "nodes_shadow", "tri_tests_closest",
-        "tri_tests_shadow", "sphere_tests_closest", "sphere_tests_shadow", "shaded_hits", "draws")]
+        "tri_tests_shadow", "sphere_tests_closest", "sphere_tests_shadow", "shaded_hits", "draws", "rays_redone")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -104,6 +104,11 @@ class OracleScene:
         self._h = C.c_void_p()
         _check(lib().pto_scene_create(C.byref(desc), C.byref(self._h)))
         self.width, self.height = desc.image_width, desc.image_height
+
+    def set_traversal(self, traversal):
+        """0 = the reference's first-child-first order (default), 1 = front to back (checks the GPU's second mode)."""
+        _check(lib().pto_scene_set_traversal(self._h, C.c_uint32(traversal)))
+        return self
 
     def close(self):
         if self._h:

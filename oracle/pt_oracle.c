@@ -50,6 +50,7 @@ struct PtoScene
     void* blocks[16];
     int num_blocks;
     int draws_per_bounce;
+    uint32_t traversal; /* PT_TRAVERSAL_* */
 };
 
 static _Thread_local char g_error[256];
@@ -97,6 +98,13 @@ int pto_scene_create( const PtSceneDesc* desc, PtoScene** out )
     return 0;
 }
 
+int pto_scene_set_traversal( PtoScene* s, uint32_t traversal )
+{
+    if ( !s || traversal > PT_TRAVERSAL_ORDERED ) return fail( "pto_scene_set_traversal: bad argument" );
+    s->traversal = traversal;
+    return 0;
+}
+
 void pto_scene_destroy( PtoScene* s )
 {
     if ( !s ) return;
@@ -108,7 +116,7 @@ void pto_scene_destroy( PtoScene* s )
 
 /* intersect::RayAABBFastest, src/intersection_tests.cpp:91-110.  Comparisons, not min/max: a NaN slab value
  * (0 * inf) makes every comparison false, so the test passes. */
-static int ray_aabb( v3 o, v3 inv, const int neg[3], const float* bmin, const float* bmax, float maxT )
+static int ray_aabb_cmp( v3 o, v3 inv, const int neg[3], const float* bmin, const float* bmax, float maxT, int inclusive )
 {
     float tMin  = ( ( neg[0] ? bmax : bmin )[0] - o.x ) * inv.x;
     float tMax  = ( ( 1 - neg[0] ? bmax : bmin )[0] - o.x ) * inv.x;
@@ -122,7 +130,13 @@ static int ray_aabb( v3 o, v3 inv, const int neg[3], const float* bmin, const fl
     if ( tMin > tzMax || tzMin > tMax ) return 0;
     if ( tzMin > tMin ) tMin = tzMin;
     if ( tzMax < tMax ) tMax = tzMax;
-    return ( tMin < maxT ) && ( tMax > 0 );
+    /* inclusive: the front-to-back order's test (tMin <= maxT), not the reference's */
+    return ( inclusive ? tMin <= maxT : tMin < maxT ) && ( tMax > 0 );
+}
+
+static int ray_aabb( v3 o, v3 inv, const int neg[3], const float* bmin, const float* bmax, float maxT )
+{
+    return ray_aabb_cmp( o, inv, neg, bmin, bmax, maxT, 0 );
 }
 
 /* intersect::RayTriangle (Moller-Trumbore), src/intersection_tests.cpp:34-66 */
@@ -179,7 +193,7 @@ typedef struct
 
 typedef struct
 {
-    uint64_t nodes, tris, spheres;
+    uint64_t nodes, tris, spheres, redone;
 } TravCount;
 
 static void triangle_vertices( const PtSceneDesc* d, const PtTriangle* tri, size_t idx[3] )
@@ -192,9 +206,14 @@ static void triangle_vertices( const PtSceneDesc* d, const PtTriangle* tri, size
 
 /* Triangle::Intersect (src/shapes.cpp:117-134) / Sphere::Intersect (src/shapes.cpp:52-76): test, and on an
  * accepted hit replace the hit record. */
-static int shape_intersect( const PtSceneDesc* d, uint32_t prim, v3 o, v3 dir, Hit* hit, TravCount* cnt )
+#define PTO_BAND ( 1.0f + 1.0f / 4096.0f ) /* front-to-back order: hits this close to the closest one are "ambiguous" */
+
+/* ambiguous == NULL: the reference's test.  Otherwise (front-to-back order): hits up to PTO_BAND times the closest
+ * distance so far are looked at, and *ambiguous tells whether a second hit lies within that band of the closest. */
+static int shape_intersect_band( const PtSceneDesc* d, uint32_t prim, v3 o, v3 dir, Hit* hit, TravCount* cnt, int* ambiguous )
 {
     const PtPrim* p = &d->prims[prim];
+    const float limit = ambiguous ? hit->t * PTO_BAND : hit->t;
     if ( p->type == PT_PRIM_TRIANGLE )
     {
         const PtTriangle* tri = &d->triangles[p->index];
@@ -202,7 +221,12 @@ static int shape_intersect( const PtSceneDesc* d, uint32_t prim, v3 o, v3 dir, H
         triangle_vertices( d, tri, i );
         float t, u, v;
         cnt->tris++;
-        if ( !ray_triangle( o, dir, ld3( d->vertices + 3 * i[0] ), ld3( d->vertices + 3 * i[1] ), ld3( d->vertices + 3 * i[2] ), &t, &u, &v, hit->t ) ) return 0;
+        if ( !ray_triangle( o, dir, ld3( d->vertices + 3 * i[0] ), ld3( d->vertices + 3 * i[1] ), ld3( d->vertices + 3 * i[2] ), &t, &u, &v, limit ) ) return 0;
+        if ( ambiguous )
+        {
+            if ( !( t < hit->t ) ) { *ambiguous = 1; return 0; }
+            *ambiguous = hit->t <= t * PTO_BAND;
+        }
         float w        = 1 - u - v;
         hit->t         = t;
         hit->material  = d->meshes[tri->mesh].material;
@@ -222,7 +246,12 @@ static int shape_intersect( const PtSceneDesc* d, uint32_t prim, v3 o, v3 dir, H
     v3 lo = mat_mul( s->world_to_local, o, 1.0f );  /* Transform::operator*( Ray ), src/transform.cpp:40-47 */
     v3 ld = mat_mul( s->world_to_local, dir, 0.0f );
     float t;
-    if ( !ray_sphere( lo, ld, V( 0, 0, 0 ), 1.0f, &t, hit->t ) ) return 0;
+    if ( !ray_sphere( lo, ld, V( 0, 0, 0 ), 1.0f, &t, limit ) ) return 0;
+    if ( ambiguous )
+    {
+        if ( !( t < hit->t ) ) { *ambiguous = 1; return 0; }
+        *ambiguous = hit->t <= t * PTO_BAND;
+    }
     hit->t        = t;
     hit->material = s->material;
     hit->position = add( o, scale( dir, t ) );
@@ -238,6 +267,11 @@ static int shape_intersect( const PtSceneDesc* d, uint32_t prim, v3 o, v3 dir, H
     hit->bu = hit->bv = 0.0f;
     hit->prim = (int)prim;
     return 1;
+}
+
+static int shape_intersect( const PtSceneDesc* d, uint32_t prim, v3 o, v3 dir, Hit* hit, TravCount* cnt )
+{
+    return shape_intersect_band( d, prim, o, dir, hit, cnt, NULL );
 }
 
 /* Triangle::TestIfHit / Sphere::TestIfHit (src/shapes.cpp:136-141, 78-82): the sphere is tested in world space */
@@ -325,6 +359,107 @@ static int bvh_occluded( const PtSceneDesc* d, v3 o, v3 dir, float tMax, TravCou
         }
     }
     return 0;
+}
+
+/* Front-to-back variants (PT_TRAVERSAL_ORDERED of include/pt_api.h) - NOT the reference's order; they exist to check
+ * the GPU library's second traversal mode: the child on the side the ray comes from first (the reference stores the
+ * split axis, src/bvh.hpp:19, and never reads it).  The reference's answer depends on its order only among hits
+ * within rounding of one another, so the closest-hit pass keeps everything within PTO_BAND of the closest distance
+ * alive (boxes entered with tMin <= PTO_BAND * t) and, when a second hit lay inside that band, runs the reference's
+ * own order afterwards and returns its answer; the counters are the sums of both passes.  A plain stack of far
+ * children here; the GPU side follows per-octant links instead, so equal per-ray counters check both. */
+static int bvh_intersect_ordered( const PtSceneDesc* d, v3 o, v3 dir, Hit* hit, TravCount* cnt )
+{
+    int stack[128];
+    int node = 0, top = 0, ambiguous = 0;
+    v3 inv   = V( 1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z );
+    int neg[3] = { inv.x < 0, inv.y < 0, inv.z < 0 };
+    const Hit start = *hit;
+    for ( ;; )
+    {
+        const PtBvhNode* n = &d->nodes[node];
+        cnt->nodes++;
+        if ( ray_aabb_cmp( o, inv, neg, n->aabb_min, n->aabb_max, hit->t * PTO_BAND, 1 ) )
+        {
+            if ( n->num_shapes > 0 )
+            {
+                for ( int s = n->offset; s < n->offset + n->num_shapes; ++s ) shape_intersect_band( d, (uint32_t)s, o, dir, hit, cnt, &ambiguous );
+                if ( top == 0 ) break;
+                node = stack[--top];
+            }
+            else if ( neg[n->axis < 3 ? n->axis : 0] )
+            {
+                stack[top++] = node + 1;
+                node         = n->offset;
+            }
+            else
+            {
+                stack[top++] = n->offset;
+                node         = node + 1;
+            }
+        }
+        else
+        {
+            if ( top == 0 ) break;
+            node = stack[--top];
+        }
+    }
+    if ( ambiguous )
+    {
+        *hit = start;
+        cnt->redone++;
+        return bvh_intersect( d, o, dir, hit, cnt );
+    }
+    return hit->t < start.t;
+}
+
+static int bvh_occluded_ordered( const PtSceneDesc* d, v3 o, v3 dir, float tMax, TravCount* cnt )
+{
+    int stack[128];
+    int node = 0, top = 0;
+    v3 inv   = V( 1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z );
+    int neg[3] = { inv.x < 0, inv.y < 0, inv.z < 0 };
+    for ( ;; )
+    {
+        const PtBvhNode* n = &d->nodes[node];
+        cnt->nodes++;
+        if ( ray_aabb( o, inv, neg, n->aabb_min, n->aabb_max, tMax ) )
+        {
+            if ( n->num_shapes > 0 )
+            {
+                for ( int s = n->offset; s < n->offset + n->num_shapes; ++s )
+                    if ( shape_test( d, (uint32_t)s, o, dir, tMax, cnt ) ) return 1;
+                if ( top == 0 ) break;
+                node = stack[--top];
+            }
+            else if ( neg[n->axis < 3 ? n->axis : 0] )
+            {
+                stack[top++] = node + 1;
+                node         = n->offset;
+            }
+            else
+            {
+                stack[top++] = n->offset;
+                node         = node + 1;
+            }
+        }
+        else
+        {
+            if ( top == 0 ) break;
+            node = stack[--top];
+        }
+    }
+    return 0;
+}
+
+static int scene_intersect( const PtoScene* s, v3 o, v3 dir, Hit* hit, TravCount* cnt )
+{
+    return s->traversal == PT_TRAVERSAL_ORDERED ? bvh_intersect_ordered( &s->d, o, dir, hit, cnt ) : bvh_intersect( &s->d, o, dir, hit, cnt );
+}
+
+static int scene_occluded_any( const PtoScene* s, v3 o, v3 dir, float tMax, TravCount* cnt )
+{
+    return s->traversal == PT_TRAVERSAL_ORDERED ? bvh_occluded_ordered( &s->d, o, dir, tMax, cnt ) : bvh_occluded( &s->d, o, dir, tMax, cnt );
 }
 
 /* ------------------------------------------------------------------------------------------------ sampling */
@@ -447,8 +582,8 @@ static float draw( Ctx* c )
 
 static int scene_occluded( Ctx* c, v3 o, v3 dir, float tMax )
 {
-    TravCount cnt = { 0, 0, 0 };
-    int r = bvh_occluded( &c->scene->d, o, dir, tMax, &cnt );
+    TravCount cnt = { 0, 0, 0, 0 };
+    int r = scene_occluded_any( c->scene, o, dir, tMax, &cnt );
     c->stats.rays_shadow++;
     c->stats.nodes_shadow += cnt.nodes;
     c->stats.tri_tests_shadow += cnt.tris;
@@ -541,12 +676,13 @@ static v3 radiance( Ctx* c, v3 o, v3 dir )
         hit.wo   = neg( dir );
         hit.t    = FLT_MAX; /* Scene::Intersect, src/scene.cpp:370-373 */
         hit.prim = -1;
-        TravCount cnt = { 0, 0, 0 };
-        int found = bvh_intersect( d, o, dir, &hit, &cnt );
+        TravCount cnt = { 0, 0, 0, 0 };
+        int found = scene_intersect( c->scene, o, dir, &hit, &cnt );
         c->stats.rays_closest++;
         c->stats.nodes_closest += cnt.nodes;
         c->stats.tri_tests_closest += cnt.tris;
         c->stats.sphere_tests_closest += cnt.spheres;
+        c->stats.rays_redone += cnt.redone;
         if ( !found )
         {
             v3 env;
@@ -622,8 +758,8 @@ int pto_intersect( const PtoScene* s, uint64_t n, const float* origins, const fl
         memset( &hit, 0, sizeof( hit ) );
         hit.t    = FLT_MAX;
         hit.prim = -1;
-        TravCount cnt = { 0, 0, 0 };
-        bvh_intersect( &s->d, ld3( origins + 3 * i ), ld3( dirs + 3 * i ), &hit, &cnt );
+        TravCount cnt = { 0, 0, 0, 0 };
+        scene_intersect( s, ld3( origins + 3 * i ), ld3( dirs + 3 * i ), &hit, &cnt );
         if ( prim ) prim[i] = hit.prim;
         if ( t ) t[i] = hit.t;
         if ( u ) u[i] = hit.bu;
@@ -650,8 +786,8 @@ int pto_occluded( const PtoScene* s, uint64_t n, const float* origins, const flo
     #pragma omp parallel for schedule( dynamic, 256 )
     for ( int64_t i = 0; i < (int64_t)n; ++i )
     {
-        TravCount cnt = { 0, 0, 0 };
-        occluded[i] = (uint8_t)bvh_occluded( &s->d, ld3( origins + 3 * i ), ld3( dirs + 3 * i ), t_max[i], &cnt );
+        TravCount cnt = { 0, 0, 0, 0 };
+        occluded[i] = (uint8_t)scene_occluded_any( s, ld3( origins + 3 * i ), ld3( dirs + 3 * i ), t_max[i], &cnt );
         if ( nodes_visited ) nodes_visited[i] = (uint32_t)cnt.nodes;
         if ( prim_tests ) prim_tests[i] = (uint32_t)( cnt.tris + cnt.spheres );
     }

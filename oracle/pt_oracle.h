@@ -35,11 +35,18 @@ typedef struct PtoStats
     uint64_t sphere_tests_closest, sphere_tests_shadow;
     uint64_t shaded_hits;
     uint64_t draws; /* Random::Rand() calls */
+    uint64_t rays_redone; /* PT_TRAVERSAL_ORDERED: closest-hit rays traced a second time in the reference's order */
 } PtoStats;
 
 /* Copies the scene arrays. */
 int  pto_scene_create( const PtSceneDesc* desc, PtoScene** out );
 void pto_scene_destroy( PtoScene* scene );
+
+/* Order in which pto_intersect / pto_occluded / pto_li_image visit the children of an inner node: PT_TRAVERSAL_REFERENCE
+ * (default; BVH::Intersect's first-child-first order, src/bvh.cpp:254-258) or PT_TRAVERSAL_ORDERED, the front-to-back
+ * order of the GPU library's second mode - not a restatement of anything in the reference; it checks that mode's
+ * per-ray counters, while its hits are checked against the reference order's. */
+int pto_scene_set_traversal( PtoScene* scene, uint32_t traversal );
 const char* pto_last_error( void );
 
 /* Scene::Intersect over a batch (src/scene.cpp:370-373, src/bvh.cpp:230-268, src/shapes.cpp:52-76,117-134).

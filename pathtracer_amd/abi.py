@@ -7,14 +7,16 @@ import ctypes as C
 
 import numpy as np
 
-PT_API_VERSION = 1
+PT_API_VERSION = 2
 
 PT_OK, PT_ERR_INVALID_ARG, PT_ERR_INVALID_SCENE, PT_ERR_DEVICE, PT_ERR_STATE = range(5)
 PT_PRIM_TRIANGLE, PT_PRIM_SPHERE = 0, 1
 PT_LIGHT_POINT, PT_LIGHT_DIRECTIONAL, PT_LIGHT_AREA = 0, 1, 2
 PT_RNG_PHILOX, PT_RNG_TABLE = 0, 1
 PT_TONEMAP_UNCHARTED2, PT_TONEMAP_REINHARD, PT_TONEMAP_NONE = 0, 1, 2
-PT_RENDER_ACCUMULATE, PT_RENDER_PROFILE = 1, 2
+PT_RENDER_ACCUMULATE, PT_RENDER_PROFILE, PT_RENDER_ORDERED = 1, 2, 4
+PT_TRAVERSAL_REFERENCE, PT_TRAVERSAL_ORDERED = 0, 1
+PT_SCENE_NO_DIRECT_SUM, PT_SCENE_TOP_BREADTH_FIRST, PT_SCENE_NO_ORDERED_LAYOUT = 1, 2, 4
 PT_K_RAYGEN, PT_K_EXTEND, PT_K_SHADE, PT_K_CONNECT, PT_K_FILM, PT_K_TONEMAP, PT_K_RESOLVE, PT_K_COUNT = range(8)
 KERNEL_NAMES = ("raygen", "extend", "shade", "connect", "film", "tonemap", "resolve")
 PTH_SPLIT_SAH, PTH_SPLIT_MIDDLE, PTH_SPLIT_EQUAL_COUNTS = 0, 1, 2
@@ -61,6 +63,7 @@ class PtSceneDesc(C.Structure):
         ("camera", PtCamera),
         ("image_width", C.c_int32), ("image_height", C.c_int32),
         ("max_depth", C.c_int32), ("device", C.c_int32),
+        ("flags", C.c_uint32), ("top_nodes", C.c_uint32),
     ]
 
 
@@ -82,6 +85,7 @@ class PtStats(C.Structure):
         ("tri_tests_closest", C.c_uint64), ("tri_tests_shadow", C.c_uint64),
         ("sphere_tests_closest", C.c_uint64), ("sphere_tests_shadow", C.c_uint64),
         ("shaded_hits", C.c_uint64), ("node_steps_closest", C.c_uint64), ("node_steps_shadow", C.c_uint64),
+        ("rays_redone", C.c_uint64),
         ("launches", C.c_uint64 * PT_K_COUNT), ("kernel_ms", C.c_double * PT_K_COUNT),
         ("render_ms", C.c_double),
     ]

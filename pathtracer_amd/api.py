@@ -55,6 +55,8 @@ def lib():
         L.pt_readback.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(abi.PtStats)]
         L.pt_trace_closest.argtypes = [C.c_void_p, C.c_uint64] + [C.c_void_p] * 8
         L.pt_trace_any.argtypes = [C.c_void_p, C.c_uint64] + [C.c_void_p] * 6
+        L.pt_trace_closest_mode.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64] + [C.c_void_p] * 8
+        L.pt_trace_any_mode.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64] + [C.c_void_p] * 6
         L.pt_film_device_ptr.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
         L.pt_clear_film.argtypes = [C.c_void_p]
         L.pt_download_film.argtypes = [C.c_void_p, C.c_void_p]
@@ -100,10 +102,12 @@ class DeviceScene:
         self.close()
 
     def render(self, spp_total, sample_begin=0, sample_end=None, seed=0, table=None, table_draws_per_sample=0,
-               accumulate=False, profile=False, samples_per_pass=0, stream=None):
+               accumulate=False, profile=False, samples_per_pass=0, stream=None, ordered=False):
+        """ordered: front-to-back traversal (PT_RENDER_ORDERED) - same film, fewer node visits."""
         p = abi.PtRenderParams()
         p.struct_size = C.sizeof(abi.PtRenderParams)
-        p.flags = (abi.PT_RENDER_ACCUMULATE if accumulate else 0) | (abi.PT_RENDER_PROFILE if profile else 0)
+        p.flags = ((abi.PT_RENDER_ACCUMULATE if accumulate else 0) | (abi.PT_RENDER_PROFILE if profile else 0)
+                   | (abi.PT_RENDER_ORDERED if ordered else 0))
         p.spp_total = int(spp_total)
         p.sample_begin = int(sample_begin)
         p.sample_end = int(spp_total if sample_end is None else sample_end)
@@ -155,20 +159,20 @@ class DeviceScene:
         _check(lib().pt_film_device_ptr(self._h, C.byref(ptr), C.byref(nbytes)))
         return ptr.value, nbytes.value
 
-    def trace_closest(self, origins, dirs):
+    def trace_closest(self, origins, dirs, traversal=abi.PT_TRAVERSAL_REFERENCE):
         o, d = _f32(origins).reshape(-1, 3), _f32(dirs).reshape(-1, 3)
         n = len(o)
         out = {"prim": np.zeros(n, np.int32), "t": np.zeros(n, np.float32), "u": np.zeros(n, np.float32),
                "v": np.zeros(n, np.float32), "nodes": np.zeros(n, np.uint32), "prim_tests": np.zeros(n, np.uint32)}
-        _check(lib().pt_trace_closest(self._h, n, o.ctypes.data, d.ctypes.data, out["prim"].ctypes.data,
-                                      out["t"].ctypes.data, out["u"].ctypes.data, out["v"].ctypes.data,
-                                      out["nodes"].ctypes.data, out["prim_tests"].ctypes.data))
+        _check(lib().pt_trace_closest_mode(self._h, traversal, n, o.ctypes.data, d.ctypes.data, out["prim"].ctypes.data,
+                                           out["t"].ctypes.data, out["u"].ctypes.data, out["v"].ctypes.data,
+                                           out["nodes"].ctypes.data, out["prim_tests"].ctypes.data))
         return out
 
-    def trace_any(self, origins, dirs, t_max):
+    def trace_any(self, origins, dirs, t_max, traversal=abi.PT_TRAVERSAL_REFERENCE):
         o, d, tm = _f32(origins).reshape(-1, 3), _f32(dirs).reshape(-1, 3), _f32(t_max)
         n = len(o)
         out = {"occluded": np.zeros(n, np.uint8), "nodes": np.zeros(n, np.uint32), "prim_tests": np.zeros(n, np.uint32)}
-        _check(lib().pt_trace_any(self._h, n, o.ctypes.data, d.ctypes.data, tm.ctypes.data, out["occluded"].ctypes.data,
-                                  out["nodes"].ctypes.data, out["prim_tests"].ctypes.data))
+        _check(lib().pt_trace_any_mode(self._h, traversal, n, o.ctypes.data, d.ctypes.data, tm.ctypes.data,
+                                       out["occluded"].ctypes.data, out["nodes"].ctypes.data, out["prim_tests"].ctypes.data))
         return out

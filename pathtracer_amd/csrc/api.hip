@@ -120,14 +120,14 @@ struct PtScene
     bool directSum = false;                         // one light with one sample: ConnectKernel adds the direct light, no ResolveKernel
 
     // scene
-    DeviceBuffer nodes, prims, triShade, spheres, materials, textures, texels, lights, skybox;
+    DeviceBuffer nodes, orderedNodes, prims, triShade, spheres, materials, textures, texels, lights, skybox;
     SceneView view{};
     PtCamera camera{};
     int width = 0, height = 0, maxDepth = 0;
     uint64_t bytesPerPathFixed = 0;
 
     // path state
-    DeviceBuffer rayO0, rayO1, rayD0, rayD1, thr0, thr1, rad, hit, shadowO, shDir, shEst, queue0, queue1, shadowPaths, shadowRays, sphereQueue, counts, cursors;
+    DeviceBuffer rayO0, rayO1, rayD0, rayD1, thr0, thr1, rad, hit, shadowO, shDir, shEst, queue0, queue1, shadowPaths, shadowRays, sphereQueue, redo, counts, cursors;
     PathBuffers paths{};
     DeviceBuffer sampleTable;
 
@@ -263,19 +263,17 @@ int Upload( PtScene* s, const PtSceneDesc* d, const std::vector< uint32_t >& esc
     // Device order of the nodes: the top of the tree first (contiguous: the traversal kernels copy its beginning
     // into LDS), sibling pairs in the order of their parents' box area, everything below in the reference's pre-order.  The traversal follows stored
     // links, so the visit sequence is the reference's whatever the order in memory.
-    uint32_t top = kTopNodes;
-    if ( const char* env = std::getenv( "PT_TOP_NODES" ) ) top = static_cast< uint32_t >( std::strtoul( env, nullptr, 10 ) );
+    uint32_t top = d->top_nodes ? d->top_nodes : kTopNodes;
     if ( top > N ) top = N;
     std::vector< uint32_t > place( N + 1, 0xFFFFFFFFu ); // reference index -> device index
+    std::vector< uint32_t > bfs; // the top of the tree: the root, then sibling pairs
     {
-        std::vector< uint32_t > bfs;
         bfs.reserve( top );
         if ( top > 0 ) bfs.push_back( 0 );
-        const char* orderEnv = std::getenv( "PT_TOP_ORDER" );
-        if ( !( orderEnv && std::strcmp( orderEnv, "bfs" ) == 0 ) )
+        if ( !( d->flags & PT_SCENE_TOP_BREADTH_FIRST ) )
         {
             // largest box first: a node is visited when its parent's box is hit, and a bigger box is hit by more rays
-            // (against plain breadth-first order, PT_TOP_ORDER=bfs: closest-hit kernel -0.5 %)
+            // (against plain breadth-first order, PT_SCENE_TOP_BREADTH_FIRST: closest-hit kernel -0.5 %)
             auto area = [&]( uint32_t i ) {
                 const PtBvhNode& n = d->nodes[i];
                 const float dx = n.aabb_max[0] - n.aabb_min[0], dy = n.aabb_max[1] - n.aabb_min[1], dz = n.aabb_max[2] - n.aabb_min[2];
@@ -330,6 +328,78 @@ int Upload( PtScene* s, const PtSceneDesc* d, const std::vector< uint32_t >& esc
         std::memcpy( &o[7], &word, 4 );
     }
     HIP_TRY( s->nodes.Upload( nodes.data(), nodes.size() * 4 ) );
+    nodes = std::vector< float >();
+
+    // Second layout, for front-to-back traversal (kernels.hip, TraceClosestOrdered): 64-byte records, the root at 0,
+    // record 1 unused, then sibling pairs at even indices - the top of the tree in the same order as above, below it
+    // every pair followed by the first child's subtree, then the second child's.  Each record carries, per octant of
+    // ray directions, the node that follows its subtree when every inner node's near child is visited first.
+    uint32_t numOrdered = 0, topOrdered = 0;
+    if ( !( d->flags & PT_SCENE_NO_ORDERED_LAYOUT ) )
+    {
+        const uint32_t unset = 0xFFFFFFFFu;
+        std::vector< uint32_t > at( N, unset ); // reference index -> record
+        at[0] = 0;
+        uint32_t next = 2;
+        for ( size_t i = 1; i + 1 < bfs.size(); i += 2 )
+        {
+            at[bfs[i]]     = next;
+            at[bfs[i + 1]] = next + 1;
+            next += 2;
+        }
+        topOrdered = next;
+        std::vector< uint32_t > stack;
+        for ( uint32_t i = 0; i < N; ++i )
+        {
+            if ( at[i] == unset || d->nodes[i].num_shapes > 0 || at[i + 1] != unset ) continue;
+            stack.push_back( i );
+            while ( !stack.empty() )
+            {
+                const uint32_t x = stack.back();
+                stack.pop_back();
+                if ( d->nodes[x].num_shapes > 0 ) continue;
+                const uint32_t a = x + 1, b = static_cast< uint32_t >( d->nodes[x].offset );
+                if ( at[a] == unset )
+                {
+                    at[a] = next;
+                    at[b] = next + 1;
+                    next += 2;
+                }
+                stack.push_back( b );
+                stack.push_back( a );
+            }
+        }
+        numOrdered = next; // N + 1
+        std::vector< uint32_t > rec( 16ull * numOrdered, 0u );
+        for ( int o = 0; o < 8; ++o ) rec[8 + o] = numOrdered; // after the root's subtree: the end
+        for ( uint32_t i = 0; i < N; ++i )                     // parents come before their children in the reference's order
+        {
+            const PtBvhNode& n = d->nodes[i];
+            uint32_t* r = &rec[16ull * at[i]];
+            std::memcpy( &r[0], &n.aabb_min[0], 4 ); std::memcpy( &r[1], &n.aabb_min[1], 4 );
+            std::memcpy( &r[2], &n.aabb_max[0], 4 ); std::memcpy( &r[3], &n.aabb_max[1], 4 );
+            std::memcpy( &r[4], &n.aabb_min[2], 4 ); std::memcpy( &r[5], &n.aabb_max[2], 4 );
+            if ( n.num_shapes > 0 )
+            {
+                r[6] = static_cast< uint32_t >( n.offset ) | ( static_cast< uint32_t >( n.num_shapes - 1 ) << 28 );
+                r[7] = kLeafFlag;
+                continue;
+            }
+            const uint32_t a = i + 1, b = static_cast< uint32_t >( n.offset );
+            const uint32_t axis = n.axis < 3 ? n.axis : 0; // any choice of the near child gives the same hits
+            r[6] = at[a];
+            r[7] = 2u + axis;
+            uint32_t* ra = &rec[16ull * at[a]];
+            uint32_t* rb = &rec[16ull * at[b]];
+            for ( uint32_t o = 0; o < 8; ++o )
+            {
+                const bool secondIsNear = ( o >> axis ) & 1u;
+                ( secondIsNear ? rb : ra )[8 + o] = secondIsNear ? at[a] : at[b]; // after the near child's subtree: its sibling
+                ( secondIsNear ? ra : rb )[8 + o] = r[8 + o];                      // after the far child's: what follows the parent
+            }
+        }
+        HIP_TRY( s->orderedNodes.Upload( rec.data(), rec.size() * 4 ) );
+    }
 
     std::vector< float > prims( 16ull * P, 0.0f ), shade( 32ull * P, 0.0f ); // 112 bytes of attributes in a 128-byte slot: one L2 line per record
     for ( uint64_t i = 0; i < P; ++i )
@@ -451,6 +521,9 @@ int Upload( PtScene* s, const PtSceneDesc* d, const std::vector< uint32_t >& esc
 
     SceneView& v    = s->view;
     v.nodes         = s->nodes.As< float4 >();
+    v.orderedNodes  = s->orderedNodes.As< float4 >();
+    v.numOrderedNodes = numOrdered;
+    v.numTopOrdered = topOrdered;
     v.prims         = s->prims.As< float4 >();
     v.triShade      = s->triShade.As< float4 >();
     v.spheres       = s->spheres.As< float4 >();
@@ -465,7 +538,7 @@ int Upload( PtScene* s, const PtSceneDesc* d, const std::vector< uint32_t >& esc
     v.numSpheres    = static_cast< uint32_t >( d->num_spheres );
     v.numLights     = static_cast< uint32_t >( d->num_lights );
     v.shadowSlots   = slots;
-    s->directSum    = d->num_lights == 1 && d->lights[0].n_samples == 1 && !std::getenv( "PT_NO_DIRECT_SUM" );
+    s->directSum    = d->num_lights == 1 && d->lights[0].n_samples == 1 && !( d->flags & PT_SCENE_NO_DIRECT_SUM );
     v.drawsPerBounce = static_cast< int32_t >( 2 * areaSamples + 2 );
     v.skyboxWidth   = d->skybox_width;
     v.skyboxHeight  = d->skybox_height;
@@ -477,20 +550,25 @@ int Upload( PtScene* s, const PtSceneDesc* d, const std::vector< uint32_t >& esc
     s->maxDepth = d->max_depth;
     // ray origin, direction and throughput double buffered, hit, radiance, shadow origin (16 B each), four queues
     // (4 B each), per shadow slot a 32 B record and a 4 B queue entry
-    s->bytesPerPathFixed = 9 * 16 + 4 * 4 + 36ull * static_cast< uint64_t >( slots > 0 ? slots : 1 );
+    s->bytesPerPathFixed = 9 * 16 + 5 * 4 + 36ull * static_cast< uint64_t >( slots > 0 ? slots : 1 );
 
     const size_t pixels = static_cast< size_t >( s->width ) * s->height;
     HIP_TRY( s->film.Allocate( pixels * 16 ) );
     HIP_TRY( hipMemset( s->film.ptr, 0, pixels * 16 ) );
     HIP_TRY( s->stats.Allocate( ST_COUNT * 8 ) );
     HIP_TRY( hipMemset( s->stats.ptr, 0, ST_COUNT * 8 ) );
-    HIP_TRY( s->cursors.Allocate( 2 * 4 * static_cast< size_t >( s->maxDepth > 0 ? s->maxDepth : 1 ) ) );
+    // per bounce: the two unit cursors of the traversal kernels and the length of the redo queue
+    HIP_TRY( s->cursors.Allocate( 3 * 4 * static_cast< size_t >( s->maxDepth > 0 ? s->maxDepth : 1 ) ) );
     return PT_OK;
 }
 
 int EnsurePathBuffers( PtScene* s, uint64_t capacity )
 {
     if ( s->paths.capacity >= capacity ) return PT_OK;
+    // Growing frees every buffer before it allocates the larger one.  Should an allocation below fail, the scene is
+    // left with no path buffers at all (capacity 0), so that the next call allocates from scratch instead of
+    // launching on freed memory.
+    s->paths = PathBuffers{};
     const uint64_t slots = s->view.shadowSlots > 0 ? s->view.shadowSlots : 1;
     // one queue segment of kUnitPaths entries per unit of paths, one length per bounce, queue and unit
     const uint64_t units   = ( capacity + kUnitPaths - 1 ) / kUnitPaths;
@@ -512,6 +590,7 @@ int EnsurePathBuffers( PtScene* s, uint64_t capacity )
     HIP_TRY( s->shadowPaths.Allocate( entries * 4 ) );
     HIP_TRY( s->shadowRays.Allocate( entries * slots * 4 ) );
     if ( s->view.numSpheres ) HIP_TRY( s->sphereQueue.Allocate( entries * 4 ) );
+    if ( s->orderedNodes.ptr ) HIP_TRY( s->redo.Allocate( entries * 4 ) );
     PathBuffers& p = s->paths;
     p.rayO[0]     = s->rayO0.As< float4 >();
     p.rayO[1]     = s->rayO1.As< float4 >();
@@ -531,6 +610,8 @@ int EnsurePathBuffers( PtScene* s, uint64_t capacity )
     p.sphereQueue = s->sphereQueue.As< uint32_t >();
     p.counts      = s->counts.As< uint32_t >();
     p.cursors     = s->cursors.As< uint32_t >();
+    p.redo        = s->redo.As< uint32_t >();
+    p.redoCount   = p.cursors + 2 * static_cast< size_t >( s->maxDepth > 0 ? s->maxDepth : 1 );
     p.capacity    = capacity;
     p.shadowSlots = static_cast< uint32_t >( slots );
     p.directSum   = s->directSum ? 1u : 0u;
@@ -727,7 +808,9 @@ try
     }
 
     const CameraFrame cam = MakeCameraFrame( s->camera, s->width, s->height );
-    const LaunchCfg cfg{ stream, s->gridBlocks, s->extendBlocks, s->connectBlocks };
+    const bool ordered = ( p->flags & PT_RENDER_ORDERED ) != 0;
+    if ( ordered && !s->orderedNodes.ptr ) return Fail( PT_ERR_STATE, "pt_render: PT_RENDER_ORDERED, but the scene was uploaded with PT_SCENE_NO_ORDERED_LAYOUT" );
+    const LaunchCfg cfg{ stream, s->gridBlocks, s->extendBlocks, s->connectBlocks, ordered };
     SpanTimer timer{ s, stream, ( p->flags & PT_RENDER_PROFILE ) != 0 };
     uint64_t* stats = s->stats.As< uint64_t >();
     PathBuffers pb = s->paths;
@@ -828,6 +911,7 @@ try
         stats->shaded_hits          = dev[ST_SHADED];
         stats->node_steps_closest   = dev[ST_STEPS_CLOSEST];
         stats->node_steps_shadow    = dev[ST_STEPS_SHADOW];
+        stats->rays_redone          = dev[ST_RAYS_REDONE];
         std::memcpy( stats->launches, s->launches, sizeof( s->launches ) );
         std::memcpy( stats->kernel_ms, s->kernelMs, sizeof( s->kernelMs ) );
         stats->render_ms = s->renderMs;
@@ -882,11 +966,13 @@ catch ( ... )
     return HostFailure( "pt_upload_film" );
 }
 
-int pt_trace_closest( PtScene* s, uint64_t n, const float* origins, const float* directions, int32_t* prim, float* t, float* u, float* v,
-                      uint32_t* nodes_visited, uint32_t* prim_tests )
+int pt_trace_closest_mode( PtScene* s, uint32_t traversal, uint64_t n, const float* origins, const float* directions, int32_t* prim, float* t,
+                           float* u, float* v, uint32_t* nodes_visited, uint32_t* prim_tests )
 try
 {
     if ( !s || ( n && ( !origins || !directions ) ) ) return Fail( PT_ERR_INVALID_ARG, "pt_trace_closest: null argument" );
+    if ( traversal > PT_TRAVERSAL_ORDERED ) return Fail( PT_ERR_INVALID_ARG, "pt_trace_closest: unknown traversal order %u", traversal );
+    if ( traversal == PT_TRAVERSAL_ORDERED && !s->orderedNodes.ptr ) return Fail( PT_ERR_STATE, "pt_trace_closest: PT_TRAVERSAL_ORDERED, but the scene was uploaded with PT_SCENE_NO_ORDERED_LAYOUT" );
     if ( n == 0 ) return PT_OK;
     HIP_TRY( hipSetDevice( s->device ) );
     DeviceBuffer dO, dD, dPrim, dT, dU, dV, dN, dP;
@@ -898,7 +984,7 @@ try
     HIP_TRY( dV.Allocate( n * 4 ) );
     HIP_TRY( dN.Allocate( n * 4 ) );
     HIP_TRY( dP.Allocate( n * 4 ) );
-    const LaunchCfg cfg{ s->stream, s->gridBlocks, s->extendBlocks, s->connectBlocks };
+    const LaunchCfg cfg{ s->stream, s->gridBlocks, s->extendBlocks, s->connectBlocks, traversal == PT_TRAVERSAL_ORDERED };
     LaunchTraceClosest( cfg, s->view, n, dO.As< float >(), dD.As< float >(), dPrim.As< int32_t >(), dT.As< float >(), dU.As< float >(),
                         dV.As< float >(), dN.As< uint32_t >(), dP.As< uint32_t >() );
     HIP_TRY( hipGetLastError() );
@@ -916,11 +1002,19 @@ catch ( ... )
     return HostFailure( "pt_trace_closest" );
 }
 
-int pt_trace_any( PtScene* s, uint64_t n, const float* origins, const float* directions, const float* t_max, uint8_t* occluded,
-                  uint32_t* nodes_visited, uint32_t* prim_tests )
+int pt_trace_closest( PtScene* s, uint64_t n, const float* origins, const float* directions, int32_t* prim, float* t, float* u, float* v,
+                      uint32_t* nodes_visited, uint32_t* prim_tests )
+{
+    return pt_trace_closest_mode( s, PT_TRAVERSAL_REFERENCE, n, origins, directions, prim, t, u, v, nodes_visited, prim_tests );
+}
+
+int pt_trace_any_mode( PtScene* s, uint32_t traversal, uint64_t n, const float* origins, const float* directions, const float* t_max,
+                       uint8_t* occluded, uint32_t* nodes_visited, uint32_t* prim_tests )
 try
 {
     if ( !s || ( n && ( !origins || !directions || !t_max || !occluded ) ) ) return Fail( PT_ERR_INVALID_ARG, "pt_trace_any: null argument" );
+    if ( traversal > PT_TRAVERSAL_ORDERED ) return Fail( PT_ERR_INVALID_ARG, "pt_trace_any: unknown traversal order %u", traversal );
+    if ( traversal == PT_TRAVERSAL_ORDERED && !s->orderedNodes.ptr ) return Fail( PT_ERR_STATE, "pt_trace_any: PT_TRAVERSAL_ORDERED, but the scene was uploaded with PT_SCENE_NO_ORDERED_LAYOUT" );
     if ( n == 0 ) return PT_OK;
     HIP_TRY( hipSetDevice( s->device ) );
     DeviceBuffer dO, dD, dT, dOcc, dN, dP;
@@ -930,7 +1024,7 @@ try
     HIP_TRY( dOcc.Allocate( n ) );
     HIP_TRY( dN.Allocate( n * 4 ) );
     HIP_TRY( dP.Allocate( n * 4 ) );
-    const LaunchCfg cfg{ s->stream, s->gridBlocks, s->extendBlocks, s->connectBlocks };
+    const LaunchCfg cfg{ s->stream, s->gridBlocks, s->extendBlocks, s->connectBlocks, traversal == PT_TRAVERSAL_ORDERED };
     LaunchTraceAny( cfg, s->view, n, dO.As< float >(), dD.As< float >(), dT.As< float >(), dOcc.As< uint8_t >(), dN.As< uint32_t >(), dP.As< uint32_t >() );
     HIP_TRY( hipGetLastError() );
     HIP_TRY( hipStreamSynchronize( s->stream ) );
@@ -942,6 +1036,12 @@ try
 catch ( ... )
 {
     return HostFailure( "pt_trace_any" );
+}
+
+int pt_trace_any( PtScene* s, uint64_t n, const float* origins, const float* directions, const float* t_max, uint8_t* occluded,
+                  uint32_t* nodes_visited, uint32_t* prim_tests )
+{
+    return pt_trace_any_mode( s, PT_TRAVERSAL_REFERENCE, n, origins, directions, t_max, occluded, nodes_visited, prim_tests );
 }
 
 } // extern "C"

@@ -83,14 +83,22 @@ __device__ __forceinline__ float4 LoadLds16( const float4* p )
     return make_float4( __uint_as_float( v.x ), __uint_as_float( v.y ), __uint_as_float( v.z ), __uint_as_float( v.w ) );
 }
 
+__device__ __forceinline__ uint32_t Load4( BufferDesc buffer, uint32_t byteOffset )
+{
+    return static_cast< uint32_t >( __builtin_amdgcn_raw_buffer_load_b32( buffer, static_cast< int >( byteOffset ), 0, 0 ) );
+}
+
 struct SceneBuffers
 {
     BufferDesc nodes, prims;
 };
 
+// kOrdered: `nodes` is the front-to-back layout (64-byte records), else the reference-order layout (32-byte records)
+template < bool kOrdered = false >
 __device__ __forceinline__ SceneBuffers MakeSceneBuffers( const SceneView& sv )
 {
-    return SceneBuffers{ MakeBuffer( sv.nodes, sv.numNodes * 32u ), MakeBuffer( sv.prims, sv.numPrims * 64u ) };
+    return SceneBuffers{ kOrdered ? MakeBuffer( sv.orderedNodes, sv.numOrderedNodes * 64u ) : MakeBuffer( sv.nodes, sv.numNodes * 32u ),
+                         MakeBuffer( sv.prims, sv.numPrims * 64u ) };
 }
 
 // std::cos / std::sin of a float in the reference: the host C library's sincosf, reproduced exactly
@@ -163,6 +171,9 @@ typedef float f2 __attribute__( ( ext_vector_type( 2 ) ) );
 
 // Node record: a = {lo.x, lo.y, hi.x, hi.y}, b = {lo.z, hi.z, link, word} - the x and y planes of either side sit
 // in adjacent registers, which is what the packed two-float subtract / multiply of the slab arithmetic wants.
+// kInclusive: the box is entered when tMin <= maxT instead of tMin < maxT - the front-to-back closest-hit traversal
+// needs it, because a primitive at exactly the distance of the closest hit so far may still win by its lower index.
+template < bool kInclusive = false >
 __device__ __forceinline__ bool RayBox( f3 o, f3 inv, bool nx, bool ny, bool nz, float4 a, float4 b, float maxT )
 {
     // Both early returns of the reference are folded into flags: once one of them would have fired the later
@@ -180,7 +191,7 @@ __device__ __forceinline__ bool RayBox( f3 o, f3 inv, bool nx, bool ny, bool nz,
     const bool missZ = ( tMin > tzMax ) | ( tzMin > tMax );
     if ( tzMin > tMin ) tMin = tzMin;
     if ( tzMax < tMax ) tMax = tzMax;
-    return !missXY & !missZ & ( tMin < maxT ) & ( tMax > 0 );
+    return !missXY & !missZ & ( kInclusive ? tMin <= maxT : tMin < maxT ) & ( tMax > 0 );
 }
 
 struct HitRecord
@@ -192,8 +203,12 @@ struct HitRecord
 // One primitive test of a closest-hit leaf: Triangle::Intersect / Sphere::Intersect (src/shapes.cpp:117-123,
 // 52-61).  The record (48 bytes of a 64-byte slot) is fetched whole before its tag is looked at (one memory round trip); the
 // triangle arithmetic runs on whatever was fetched and is discarded for a sphere record.
-template < bool kSpheres = true >
-__device__ __forceinline__ void ClosestPrimTest( const SceneView& sv, const SceneBuffers& sb, uint32_t prim, f3 o, f3 d, HitRecord& h, bool* wasSphere )
+// kOrdered (front-to-back traversal, see TraceClosestOrdered): the test accepts hits up to kBand times the closest
+// distance so far, and `ambiguous` records whether a second hit lies within that band of the closest one.
+constexpr float kBand = 1.0f + 1.0f / 4096.0f;
+
+template < bool kSpheres = true, bool kOrdered = false >
+__device__ __forceinline__ void ClosestPrimTest( const SceneView& sv, const SceneBuffers& sb, uint32_t prim, f3 o, f3 d, HitRecord& h, bool* wasSphere, bool* ambiguous = nullptr )
 {
     float4 q0 = Load16( sb.prims, 64u * prim );
     const float4 q1 = Load16( sb.prims, 64u * prim + 16u ), q2 = Load16( sb.prims, 64u * prim + 32u );
@@ -201,7 +216,8 @@ __device__ __forceinline__ void ClosestPrimTest( const SceneView& sv, const Scen
     // behind that branch: a second memory round trip per leaf.  The empty statement pins the load up here.
     if constexpr ( !kSpheres ) asm volatile( "" : "+v"( q0.x ), "+v"( q0.y ), "+v"( q0.z ) );
     float t = 0.0f, u = 0.0f, v = 0.0f;
-    bool hit   = RayTriangle( o, d, F3( q0 ), F3( q1 ), F3( q2 ), h.t, &t, &u, &v );
+    const float limit = kOrdered ? h.t * kBand : h.t;
+    bool hit   = RayTriangle( o, d, F3( q0 ), F3( q1 ), F3( q2 ), limit, &t, &u, &v );
     *wasSphere = kSpheres && __float_as_uint( q0.w ) != kTagTriangle; // a scene without spheres has triangle records only
     if ( *wasSphere )
     {
@@ -211,9 +227,20 @@ __device__ __forceinline__ void ClosestPrimTest( const SceneView& sv, const Scen
         f3 lo = MatMul( c0, c1, c2, c3, o, 1.0f );
         f3 ld = MatMul( c0, c1, c2, c3, d, 0.0f );
         u = v = 0.0f;
-        hit   = RaySphere( lo, ld, F3( 0.0f, 0.0f, 0.0f ), 1.0f, h.t, &t );
+        hit   = RaySphere( lo, ld, F3( 0.0f, 0.0f, 0.0f ), 1.0f, limit, &t );
     }
-    if ( hit ) h = HitRecord{ t, u, v, static_cast< int >( prim ) };
+    if constexpr ( kOrdered )
+    {
+        if ( hit && t < h.t )
+        {
+            *ambiguous = h.t <= t * kBand; // the hit it replaces was within the band of the new one (else everything so far lies beyond it)
+            h          = HitRecord{ t, u, v, static_cast< int >( prim ) };
+        }
+        else if ( hit )
+            *ambiguous = true;
+    }
+    else if ( hit )
+        h = HitRecord{ t, u, v, static_cast< int >( prim ) };
 }
 
 // One primitive test of an any-hit leaf: TestIfHit (src/shapes.cpp:78-82, 136-141), spheres in world space.
@@ -281,6 +308,100 @@ __device__ __forceinline__ bool TraceAny( const SceneView& sv, const SceneBuffer
         node = link & ~kLeafFlag;
         if ( !boxHit ) continue;
         const uint32_t first = leaf & kLeafFirstMask, count = ( leaf >> 28 ) + 1;
+        for ( uint32_t k = 0; k < count; ++k )
+        {
+            bool wasSphere;
+            const bool hit = AnyPrimTest( sb, first + k, o, d, tMax, &wasSphere );
+            cnt.tris += wasSphere ? 0 : 1;
+            cnt.spheres += wasSphere ? 1 : 0;
+            if ( hit ) return true;
+        }
+    }
+    return false;
+}
+
+// ---- front-to-back traversal ----------------------------------------------------------------------------
+//
+// The reference stores the split axis in every inner node (src/bvh.hpp:19) and never reads it (src/bvh.cpp:254-258).
+// Here it picks the child to visit first: the one on the side the ray comes from.  For a fixed sign of the three
+// direction components (an octant) that order is again a fixed pre-order of the tree, so the stackless scheme
+// carries over: every node of the second device layout holds eight links, one per octant, each the node that
+// follows the node's subtree in that octant's order.
+//   record (64 bytes): {lo.x, lo.y, hi.x, hi.y} {lo.z, hi.z, w0, w1} {link[0..3]} {link[4..7]}
+//   inner node: w0 = device index of its first child (the second child is the next record, both in one 128-byte
+//               line), w1 = 2 + split axis;  leaf: w0 = leaf word, w1 = kLeafFlag
+// A ray keeps linkOffset = 32 + 4 * octant: the byte offset of its link inside a record; bit (2 + axis) of that
+// number is the sign of the ray along the axis, i.e. whether the second child is the near one.
+// What keeps the closest hit the reference's.  The reference meets the primitives in index order and culls a box
+// against the closest distance found so far, so where several hits lie within rounding of one another (coplanar
+// or coincident surfaces, shared edges) its answer depends on its order: a box whose computed entry distance
+// exceeds the distance of the primitive inside it by an ulp is skipped or not depending on what was found before.
+// Only hits that close to the closest one can be involved.  The front-to-back pass therefore enters every box
+// with tMin <= kBand * t, tests its primitives against the same limit, and notes whether a second hit lies within
+// kBand of the closest: such a ray is ambiguous and is traced again in the reference's order (the rest of the
+// tree cannot change the reference's answer for the others: a farther hit only ever culls boxes beyond the band).
+__device__ __forceinline__ uint32_t LinkOffset( bool nx, bool ny, bool nz ) { return 32u + 4u * ( ( nx ? 1u : 0u ) | ( ny ? 2u : 0u ) | ( nz ? 4u : 0u ) ); }
+__device__ __forceinline__ uint32_t NearChild( uint32_t w0, uint32_t w1, uint32_t linkOffset ) { return w0 + ( ( linkOffset >> ( w1 & 7u ) ) & 1u ); }
+
+__device__ __forceinline__ HitRecord TraceClosestOrdered( const SceneView& sv, const SceneBuffers& sb, f3 o, f3 d, Counters& cnt, bool* ambiguous )
+{
+    HitRecord h{ FLT_MAX, 0.0f, 0.0f, -1 };
+    const f3 inv  = F3( 1.0f / d.x, 1.0f / d.y, 1.0f / d.z );
+    const bool nx = inv.x < 0, ny = inv.y < 0, nz = inv.z < 0;
+    const uint32_t linkOffset = LinkOffset( nx, ny, nz );
+    const uint32_t end = sv.numOrderedNodes;
+    uint32_t node = 0;
+    *ambiguous = false;
+    while ( node != end )
+    {
+        const float4 a = Load16( sb.nodes, 64u * node ), b = Load16( sb.nodes, 64u * node + 16u );
+        const uint32_t link = Load4( sb.nodes, 64u * node + linkOffset );
+        cnt.nodes++;
+        const uint32_t w0 = __float_as_uint( b.z ), w1 = __float_as_uint( b.w );
+        const bool boxHit = RayBox< true >( o, inv, nx, ny, nz, a, b, h.t * kBand );
+        if ( boxHit && !( w1 & kLeafFlag ) )
+        {
+            node = NearChild( w0, w1, linkOffset );
+            continue;
+        }
+        node = link;
+        if ( !boxHit ) continue;
+        const uint32_t first = w0 & kLeafFirstMask, count = ( w0 >> 28 ) + 1;
+        for ( uint32_t k = 0; k < count; ++k )
+        {
+            bool wasSphere;
+            ClosestPrimTest< true, true >( sv, sb, first + k, o, d, h, &wasSphere, ambiguous );
+            cnt.tris += wasSphere ? 0 : 1;
+            cnt.spheres += wasSphere ? 1 : 0;
+        }
+    }
+    return h;
+}
+
+// Any hit, near child first.  The box test keeps the reference's strict comparison against the fixed tMax, so the
+// set of primitives that can be reached - and with it the answer - is the reference's whatever the order.
+__device__ __forceinline__ bool TraceAnyOrdered( const SceneView& sv, const SceneBuffers& sb, f3 o, f3 d, float tMax, Counters& cnt )
+{
+    const f3 inv  = F3( 1.0f / d.x, 1.0f / d.y, 1.0f / d.z );
+    const bool nx = inv.x < 0, ny = inv.y < 0, nz = inv.z < 0;
+    const uint32_t linkOffset = LinkOffset( nx, ny, nz );
+    const uint32_t end = sv.numOrderedNodes;
+    uint32_t node = 0;
+    while ( node != end )
+    {
+        const float4 a = Load16( sb.nodes, 64u * node ), b = Load16( sb.nodes, 64u * node + 16u );
+        const uint32_t link = Load4( sb.nodes, 64u * node + linkOffset );
+        cnt.nodes++;
+        const uint32_t w0 = __float_as_uint( b.z ), w1 = __float_as_uint( b.w );
+        const bool boxHit = RayBox( o, inv, nx, ny, nz, a, b, tMax );
+        if ( boxHit && !( w1 & kLeafFlag ) )
+        {
+            node = NearChild( w0, w1, linkOffset );
+            continue;
+        }
+        node = link;
+        if ( !boxHit ) continue;
+        const uint32_t first = w0 & kLeafFirstMask, count = ( w0 >> 28 ) + 1;
         for ( uint32_t k = 0; k < count; ++k )
         {
             bool wasSphere;
@@ -664,25 +785,30 @@ constexpr int kTraverseBurst = PT_TRAVERSE_BURST;
 
 // Closest hits of the rays entering `bounce`: BVH::Intersect (src/bvh.cpp:230-268) under Scene::Intersect
 // (src/scene.cpp:370-373).
-template < bool kSpheres >
+// kOrdered: front-to-back traversal over the second node layout (see TraceClosestOrdered); the LDS copy then holds
+// half as many records, each twice the size.
+template < bool kSpheres, bool kOrdered >
 __global__ __launch_bounds__( kSpheres ? kTraverseBlock : kTriangleBlock ) __attribute__( ( amdgpu_waves_per_eu( kSpheres ? PT_TRAVERSE_WAVES : PT_TRIANGLE_WAVES, kSpheres ? PT_TRAVERSE_WAVES : PT_TRIANGLE_WAVES ) ) ) void ExtendKernel( SceneView sv, PathBuffers pb, int bounce, uint32_t numPaths, uint64_t* stats )
 {
     UnitStream stream{ pb.cursors + 2 * bounce, bounce == 0 ? nullptr : UnitCount( pb, bounce - 1, kCountNextPaths, 0 ), pb.units, kUnitPaths, numPaths };
     const float4* rayO = pb.rayO[bounce & 1];
     const float4* rayD = pb.rayD[bounce & 1];
-    const uint32_t end    = sv.numNodes;
-    const SceneBuffers sb = MakeSceneBuffers( sv );
+    const uint32_t end    = kOrdered ? sv.numOrderedNodes : sv.numNodes;
+    const SceneBuffers sb = MakeSceneBuffers< kOrdered >( sv );
     __shared__ float4 topLds[kLdsTopNodes > 0 ? 2 * kLdsTopNodes : 1];
-    const uint32_t topCount = kLdsTopNodes < sv.numTopNodes ? kLdsTopNodes : sv.numTopNodes;
+    const uint32_t topCount = kOrdered ? ( kLdsTopNodes / 2 < sv.numTopOrdered ? kLdsTopNodes / 2 : sv.numTopOrdered )
+                                       : ( kLdsTopNodes < sv.numTopNodes ? kLdsTopNodes : sv.numTopNodes );
     if ( kLdsTopNodes > 0 )
     {
-        for ( uint32_t i = threadIdx.x; i < 2 * topCount; i += ( kSpheres ? kTraverseBlock : kTriangleBlock ) ) topLds[i] = Load16( sb.nodes, 16u * i );
+        for ( uint32_t i = threadIdx.x; i < ( kOrdered ? 4 : 2 ) * topCount; i += ( kSpheres ? kTraverseBlock : kTriangleBlock ) ) topLds[i] = Load16( sb.nodes, 16u * i );
         __syncthreads();
     }
     // node: the node to visit next (or, while a leaf is pending, the node to go to after it); leaf: pending leaf word
     uint32_t entry = kNoRay, node = end, leaf = kInnerNode; // entry: the lane's ray, as its position in the bounce's queue
     f3 o = F3( 0.0f, 0.0f, 0.0f ), d = o, inv = o;
     bool nx = false, ny = false, nz = false;
+    uint32_t linkOffset = 32u; // kOrdered: byte offset of the ray's link in a node record
+    bool ambiguous = false;    // kOrdered: a second hit within kBand of the closest one, see TraceClosestOrdered
     HitRecord h{ FLT_MAX, 0.0f, 0.0f, -1 };
     uint32_t waveRays = 0, waveNodes = 0, waveTris = 0, waveSpheres = 0, waveSteps = 0; // whole-wave totals, wave-uniform
 
@@ -699,6 +825,11 @@ __global__ __launch_bounds__( kSpheres ? kTraverseBlock : kTriangleBlock ) __att
         if ( mRay && ( __popcll( mRay ) >= kExtendRefillLanes || ( mTrav | mLeaf ) == 0 ) )
         {
             if ( idle && entry != kNoRay ) pb.hit[entry] = make_float4( h.t, h.u, h.v, __int_as_float( h.prim ) );
+            if constexpr ( kOrdered )
+            {
+                // ambiguous rays are traced again in the reference's order by RedoKernel (rare: one atomic each)
+                if ( idle && entry != kNoRay && ambiguous ) pb.redo[atomicAdd( pb.redoCount + bounce, 1u )] = entry;
+            }
             if ( idle ) entry = kNoRay;
             while ( !stream.ended )
             {
@@ -718,7 +849,9 @@ __global__ __launch_bounds__( kSpheres ? kTraverseBlock : kTriangleBlock ) __att
                     d   = F3( rayD[entry] );
                     inv = F3( 1.0f / d.x, 1.0f / d.y, 1.0f / d.z ); // bvh.cpp:235-236
                     nx = inv.x < 0; ny = inv.y < 0; nz = inv.z < 0;
+                    if constexpr ( kOrdered ) linkOffset = LinkOffset( nx, ny, nz );
                     h    = HitRecord{ FLT_MAX, 0.0f, 0.0f, -1 };     // scene.cpp:372
+                    ambiguous = false;
                     node = 0;
                 }
                 const uint32_t given = asking < left ? asking : left;
@@ -736,7 +869,7 @@ __global__ __launch_bounds__( kSpheres ? kTraverseBlock : kTriangleBlock ) __att
                 bool isTri = false, isSphere = false;
                 if ( k < shapes )
                 {
-                    ClosestPrimTest< kSpheres >( sv, sb, first + k, o, d, h, &isSphere );
+                    ClosestPrimTest< kSpheres, kOrdered >( sv, sb, first + k, o, d, h, &isSphere, &ambiguous );
                     isTri = !isSphere;
                 }
                 waveTris += LanesSet( isTri );
@@ -757,25 +890,54 @@ __global__ __launch_bounds__( kSpheres ? kTraverseBlock : kTriangleBlock ) __att
             waveSteps++;
             if ( go )
             {
-                float4 a, b;
-                if ( kLdsTopNodes > 0 && node < topCount )
+                if constexpr ( kOrdered )
                 {
-                    a = LoadLds16( topLds + 2 * node );
-                    b = LoadLds16( topLds + 2 * node + 1 );
+                    float4 a, b;
+                    uint32_t link;
+                    if ( kLdsTopNodes > 0 && node < topCount )
+                    {
+                        a    = LoadLds16( topLds + 4 * node );
+                        b    = LoadLds16( topLds + 4 * node + 1 );
+                        link = *reinterpret_cast< const uint32_t* >( reinterpret_cast< const char* >( topLds ) + 64u * node + linkOffset );
+                    }
+                    else
+                    {
+                        a    = Load16( sb.nodes, 64u * node );
+                        b    = Load16( sb.nodes, 64u * node + 16u );
+                        link = Load4( sb.nodes, 64u * node + linkOffset );
+                    }
+                    const uint32_t w0 = __float_as_uint( b.z ), w1 = __float_as_uint( b.w );
+                    const bool boxHit = RayBox< true >( o, inv, nx, ny, nz, a, b, h.t * kBand );
+                    if ( boxHit && !( w1 & kLeafFlag ) )
+                        node = NearChild( w0, w1, linkOffset );
+                    else
+                    {
+                        node = link;
+                        if ( boxHit ) leaf = w0;
+                    }
                 }
                 else
                 {
-                    a = Load16( sb.nodes, 32u * node );
-                    b = Load16( sb.nodes, 32u * node + 16u );
-                }
-                const uint32_t link = __float_as_uint( b.z ), word = __float_as_uint( b.w );
-                const bool boxHit = RayBox( o, inv, nx, ny, nz, a, b, h.t );
-                if ( boxHit && !( link & kLeafFlag ) )
-                    node = word; // first child
-                else
-                {
-                    node = link & ~kLeafFlag;
-                    if ( boxHit ) leaf = word;
+                    float4 a, b;
+                    if ( kLdsTopNodes > 0 && node < topCount )
+                    {
+                        a = LoadLds16( topLds + 2 * node );
+                        b = LoadLds16( topLds + 2 * node + 1 );
+                    }
+                    else
+                    {
+                        a = Load16( sb.nodes, 32u * node );
+                        b = Load16( sb.nodes, 32u * node + 16u );
+                    }
+                    const uint32_t link = __float_as_uint( b.z ), word = __float_as_uint( b.w );
+                    const bool boxHit = RayBox( o, inv, nx, ny, nz, a, b, h.t );
+                    if ( boxHit && !( link & kLeafFlag ) )
+                        node = word; // first child
+                    else
+                    {
+                        node = link & ~kLeafFlag;
+                        if ( boxHit ) leaf = word;
+                    }
                 }
             }
         }
@@ -787,30 +949,53 @@ __global__ __launch_bounds__( kSpheres ? kTraverseBlock : kTriangleBlock ) __att
     FlushWaveCounter( stats, ST_STEPS_CLOSEST, waveSteps );
 }
 
+// The rays ExtendKernel< ., true > found ambiguous, traced again in the reference's order (BVH::Intersect,
+// src/bvh.cpp:230-268) over the reference-order layout: one thread per ray, the result replaces the first one.
+__global__ __launch_bounds__( kBlock ) void RedoKernel( SceneView sv, PathBuffers pb, int bounce, uint64_t* stats )
+{
+    const uint32_t count = pb.redoCount[bounce];
+    const SceneBuffers sb = MakeSceneBuffers< false >( sv );
+    Counters cnt;
+    uint32_t rays = 0;
+    for ( uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < count; i += gridDim.x * kBlock )
+    {
+        const uint32_t entry = pb.redo[i];
+        const HitRecord h = TraceClosest( sv, sb, F3( pb.rayO[bounce & 1][entry] ), F3( pb.rayD[bounce & 1][entry] ), cnt );
+        pb.hit[entry] = make_float4( h.t, h.u, h.v, __int_as_float( h.prim ) );
+        rays++;
+    }
+    FlushCounter( stats, ST_RAYS_REDONE, rays );
+    FlushCounter( stats, ST_NODES_CLOSEST, cnt.nodes );
+    FlushCounter( stats, ST_TRI_CLOSEST, cnt.tris );
+    FlushCounter( stats, ST_SPH_CLOSEST, cnt.spheres );
+}
+
 // Visibility of the queued shadow rays: BVH::Occluded (src/bvh.cpp:270-310) under Scene::Occluded
 // (src/scene.cpp:381-384), same scheduling as ExtendKernel.  One work item per shadow record; an occluded
 // record gets the distance -2 written back, so that ResolveKernel leaves it out of the sum.  kDirectSum: the
 // scene has one light with one sample, so a path has at most one record per bounce and its record holds
 // throughput * LDirect and the path id (ShadeKernel): an unoccluded record is added to the path's radiance
 // here (path_tracer.cpp:133-134) and ResolveKernel does not run.
-template < bool kDirectSum >
+template < bool kDirectSum, bool kOrdered >
 __global__ __launch_bounds__( kConnectBlock ) PT_CONNECT_OCCUPANCY void ConnectKernel( SceneView sv, PathBuffers pb, int bounce, uint64_t* stats )
 {
     UnitStream stream{ pb.cursors + 2 * bounce + 1, UnitCount( pb, bounce, kCountShadowRays, 0 ), pb.units, kUnitPaths * pb.shadowSlots, 0u };
-    const uint32_t end      = sv.numNodes;
+    const uint32_t end      = kOrdered ? sv.numOrderedNodes : sv.numNodes;
     const uint32_t entries  = pb.units * kUnitPaths;
-    const SceneBuffers sb   = MakeSceneBuffers( sv );
+    const SceneBuffers sb   = MakeSceneBuffers< kOrdered >( sv );
     __shared__ float4 topLds[kLdsTopNodes > 0 ? 2 * kLdsTopNodes : 1];
-    const uint32_t topCount = kLdsTopNodes < sv.numTopNodes ? kLdsTopNodes : sv.numTopNodes;
+    const uint32_t topCount = kOrdered ? ( kLdsTopNodes / 2 < sv.numTopOrdered ? kLdsTopNodes / 2 : sv.numTopOrdered )
+                                       : ( kLdsTopNodes < sv.numTopNodes ? kLdsTopNodes : sv.numTopNodes );
     if ( kLdsTopNodes > 0 )
     {
-        for ( uint32_t i = threadIdx.x; i < 2 * topCount; i += kConnectBlock ) topLds[i] = Load16( sb.nodes, 16u * i );
+        for ( uint32_t i = threadIdx.x; i < ( kOrdered ? 4 : 2 ) * topCount; i += kConnectBlock ) topLds[i] = Load16( sb.nodes, 16u * i );
         __syncthreads();
     }
     uint32_t rec = kNoRay, node = end, leaf = kInnerNode;
     f3 o = F3( 0.0f, 0.0f, 0.0f ), d = o, inv = o;
     float tMax = 0.0f;
     bool nx = false, ny = false, nz = false, occluded = false;
+    uint32_t linkOffset = 32u; // kOrdered: byte offset of the ray's link in a node record
     uint32_t waveRays = 0, waveNodes = 0, waveTris = 0, waveSpheres = 0, waveSteps = 0; // whole-wave totals, wave-uniform
 
     for ( ;; )
@@ -861,6 +1046,7 @@ __global__ __launch_bounds__( kConnectBlock ) PT_CONNECT_OCCUPANCY void ConnectK
                     tMax = dir.w;
                     inv  = F3( 1.0f / d.x, 1.0f / d.y, 1.0f / d.z ); // bvh.cpp:275-276
                     nx = inv.x < 0; ny = inv.y < 0; nz = inv.z < 0;
+                    if constexpr ( kOrdered ) linkOffset = LinkOffset( nx, ny, nz );
                     occluded = false;
                     node     = 0;
                 }
@@ -905,25 +1091,54 @@ __global__ __launch_bounds__( kConnectBlock ) PT_CONNECT_OCCUPANCY void ConnectK
             waveSteps++;
             if ( go )
             {
-                float4 a, b;
-                if ( kLdsTopNodes > 0 && node < topCount )
+                if constexpr ( kOrdered )
                 {
-                    a = LoadLds16( topLds + 2 * node );
-                    b = LoadLds16( topLds + 2 * node + 1 );
+                    float4 a, b;
+                    uint32_t link;
+                    if ( kLdsTopNodes > 0 && node < topCount )
+                    {
+                        a    = LoadLds16( topLds + 4 * node );
+                        b    = LoadLds16( topLds + 4 * node + 1 );
+                        link = *reinterpret_cast< const uint32_t* >( reinterpret_cast< const char* >( topLds ) + 64u * node + linkOffset );
+                    }
+                    else
+                    {
+                        a    = Load16( sb.nodes, 64u * node );
+                        b    = Load16( sb.nodes, 64u * node + 16u );
+                        link = Load4( sb.nodes, 64u * node + linkOffset );
+                    }
+                    const uint32_t w0 = __float_as_uint( b.z ), w1 = __float_as_uint( b.w );
+                    const bool boxHit = RayBox( o, inv, nx, ny, nz, a, b, tMax );
+                    if ( boxHit && !( w1 & kLeafFlag ) )
+                        node = NearChild( w0, w1, linkOffset );
+                    else
+                    {
+                        node = link;
+                        if ( boxHit ) leaf = w0;
+                    }
                 }
                 else
                 {
-                    a = Load16( sb.nodes, 32u * node );
-                    b = Load16( sb.nodes, 32u * node + 16u );
-                }
-                const uint32_t link = __float_as_uint( b.z ), word = __float_as_uint( b.w );
-                const bool boxHit = RayBox( o, inv, nx, ny, nz, a, b, tMax );
-                if ( boxHit && !( link & kLeafFlag ) )
-                    node = word; // first child
-                else
-                {
-                    node = link & ~kLeafFlag;
-                    if ( boxHit ) leaf = word;
+                    float4 a, b;
+                    if ( kLdsTopNodes > 0 && node < topCount )
+                    {
+                        a = LoadLds16( topLds + 2 * node );
+                        b = LoadLds16( topLds + 2 * node + 1 );
+                    }
+                    else
+                    {
+                        a = Load16( sb.nodes, 32u * node );
+                        b = Load16( sb.nodes, 32u * node + 16u );
+                    }
+                    const uint32_t link = __float_as_uint( b.z ), word = __float_as_uint( b.w );
+                    const bool boxHit = RayBox( o, inv, nx, ny, nz, a, b, tMax );
+                    if ( boxHit && !( link & kLeafFlag ) )
+                        node = word; // first child
+                    else
+                    {
+                        node = link & ~kLeafFlag;
+                        if ( boxHit ) leaf = word;
+                    }
                 }
             }
         }
@@ -1309,13 +1524,22 @@ __global__ __launch_bounds__( kBlock ) void TonemapKernel( const float4* film, f
 }
 
 // Batch queries behind pt_trace_closest / pt_trace_any: device arrays of n rays, one thread per ray.
+template < bool kOrdered >
 __global__ __launch_bounds__( kBlock ) void TraceClosestKernel( SceneView sv, uint64_t n, const float* origins, const float* dirs, int32_t* prim,
                                                                float* t, float* u, float* v, uint32_t* nodes, uint32_t* tests )
 {
     for ( uint64_t i = static_cast< uint64_t >( blockIdx.x ) * kBlock + threadIdx.x; i < n; i += static_cast< uint64_t >( gridDim.x ) * kBlock )
     {
         Counters cnt;
-        HitRecord h = TraceClosest( sv, MakeSceneBuffers( sv ), F3( origins + 3 * i ), F3( dirs + 3 * i ), cnt );
+        HitRecord h;
+        if constexpr ( kOrdered )
+        {
+            bool ambiguous;
+            h = TraceClosestOrdered( sv, MakeSceneBuffers< true >( sv ), F3( origins + 3 * i ), F3( dirs + 3 * i ), cnt, &ambiguous );
+            if ( ambiguous ) h = TraceClosest( sv, MakeSceneBuffers< false >( sv ), F3( origins + 3 * i ), F3( dirs + 3 * i ), cnt );
+        }
+        else
+            h = TraceClosest( sv, MakeSceneBuffers< false >( sv ), F3( origins + 3 * i ), F3( dirs + 3 * i ), cnt );
         if ( prim ) prim[i] = h.prim;
         if ( t ) t[i] = h.t;
         if ( u ) u[i] = h.u;
@@ -1325,13 +1549,15 @@ __global__ __launch_bounds__( kBlock ) void TraceClosestKernel( SceneView sv, ui
     }
 }
 
+template < bool kOrdered >
 __global__ __launch_bounds__( kBlock ) void TraceAnyKernel( SceneView sv, uint64_t n, const float* origins, const float* dirs, const float* tMax,
                                                            uint8_t* occluded, uint32_t* nodes, uint32_t* tests )
 {
     for ( uint64_t i = static_cast< uint64_t >( blockIdx.x ) * kBlock + threadIdx.x; i < n; i += static_cast< uint64_t >( gridDim.x ) * kBlock )
     {
         Counters cnt;
-        bool occ = TraceAny( sv, MakeSceneBuffers( sv ), F3( origins + 3 * i ), F3( dirs + 3 * i ), tMax[i], cnt );
+        bool occ = kOrdered ? TraceAnyOrdered( sv, MakeSceneBuffers< true >( sv ), F3( origins + 3 * i ), F3( dirs + 3 * i ), tMax[i], cnt )
+                            : TraceAny( sv, MakeSceneBuffers< false >( sv ), F3( origins + 3 * i ), F3( dirs + 3 * i ), tMax[i], cnt );
         occluded[i] = occ ? 1 : 0;
         if ( nodes ) nodes[i] = cnt.nodes;
         if ( tests ) tests[i] = cnt.tris + cnt.spheres;
@@ -1354,10 +1580,10 @@ static dim3 UnitGrid( const PathBuffers& pb ) { return dim3( ( pb.units + kBlock
 void TraversalOccupancy( bool spheres, int* extendBlocksPerCu, int* connectBlocksPerCu )
 {
     int e = 0, c = 0;
-    const hipError_t rc = spheres ? hipOccupancyMaxActiveBlocksPerMultiprocessor( &e, ExtendKernel< true >, kTraverseBlock, 0 )
-                                  : hipOccupancyMaxActiveBlocksPerMultiprocessor( &e, ExtendKernel< false >, kTriangleBlock, 0 );
+    const hipError_t rc = spheres ? hipOccupancyMaxActiveBlocksPerMultiprocessor( &e, ExtendKernel< true, true >, kTraverseBlock, 0 )
+                                  : hipOccupancyMaxActiveBlocksPerMultiprocessor( &e, ExtendKernel< false, true >, kTriangleBlock, 0 );
     if ( rc != hipSuccess || e < 1 ) e = 2;
-    if ( hipOccupancyMaxActiveBlocksPerMultiprocessor( &c, ConnectKernel< false >, kConnectBlock, 0 ) != hipSuccess || c < 1 ) c = 4;
+    if ( hipOccupancyMaxActiveBlocksPerMultiprocessor( &c, ConnectKernel< false, true >, kConnectBlock, 0 ) != hipSuccess || c < 1 ) c = 4;
     *extendBlocksPerCu  = e;
     *connectBlocksPerCu = c;
 }
@@ -1370,10 +1596,16 @@ void LaunchRaygen( const LaunchCfg& cfg, const CameraFrame& cam, const RngParams
 
 void LaunchExtend( const LaunchCfg& cfg, const SceneView& sv, const PathBuffers& pb, int bounce, uint32_t numPaths, uint64_t* stats )
 {
-    if ( sv.numSpheres )
-        hipLaunchKernelGGL( ExtendKernel< true >, dim3( cfg.extendBlocks ), dim3( kTraverseBlock ), 0, cfg.stream, sv, pb, bounce, numPaths, stats );
+    const dim3 grid( cfg.extendBlocks ), block( sv.numSpheres ? kTraverseBlock : kTriangleBlock );
+    if ( sv.numSpheres && cfg.ordered )
+        hipLaunchKernelGGL( ( ExtendKernel< true, true > ), grid, block, 0, cfg.stream, sv, pb, bounce, numPaths, stats );
+    else if ( sv.numSpheres )
+        hipLaunchKernelGGL( ( ExtendKernel< true, false > ), grid, block, 0, cfg.stream, sv, pb, bounce, numPaths, stats );
+    else if ( cfg.ordered )
+        hipLaunchKernelGGL( ( ExtendKernel< false, true > ), grid, block, 0, cfg.stream, sv, pb, bounce, numPaths, stats );
     else
-        hipLaunchKernelGGL( ExtendKernel< false >, dim3( cfg.extendBlocks ), dim3( kTriangleBlock ), 0, cfg.stream, sv, pb, bounce, numPaths, stats );
+        hipLaunchKernelGGL( ( ExtendKernel< false, false > ), grid, block, 0, cfg.stream, sv, pb, bounce, numPaths, stats );
+    if ( cfg.ordered ) hipLaunchKernelGGL( RedoKernel, dim3( 256 ), dim3( kBlock ), 0, cfg.stream, sv, pb, bounce, stats );
 }
 
 void LaunchShade( const LaunchCfg& cfg, const SceneView& sv, const RngParams& rng, const PathBuffers& pb, int bounce, int maxDepth,
@@ -1389,10 +1621,15 @@ void LaunchShade( const LaunchCfg& cfg, const SceneView& sv, const RngParams& rn
 
 void LaunchConnect( const LaunchCfg& cfg, const SceneView& sv, const PathBuffers& pb, int bounce, uint64_t* stats )
 {
-    if ( pb.directSum )
-        hipLaunchKernelGGL( ConnectKernel< true >, dim3( cfg.connectBlocks ), dim3( kConnectBlock ), 0, cfg.stream, sv, pb, bounce, stats );
+    const dim3 grid( cfg.connectBlocks ), block( kConnectBlock );
+    if ( pb.directSum && cfg.ordered )
+        hipLaunchKernelGGL( ( ConnectKernel< true, true > ), grid, block, 0, cfg.stream, sv, pb, bounce, stats );
+    else if ( pb.directSum )
+        hipLaunchKernelGGL( ( ConnectKernel< true, false > ), grid, block, 0, cfg.stream, sv, pb, bounce, stats );
+    else if ( cfg.ordered )
+        hipLaunchKernelGGL( ( ConnectKernel< false, true > ), grid, block, 0, cfg.stream, sv, pb, bounce, stats );
     else
-        hipLaunchKernelGGL( ConnectKernel< false >, dim3( cfg.connectBlocks ), dim3( kConnectBlock ), 0, cfg.stream, sv, pb, bounce, stats );
+        hipLaunchKernelGGL( ( ConnectKernel< false, false > ), grid, block, 0, cfg.stream, sv, pb, bounce, stats );
 }
 
 void LaunchResolve( const LaunchCfg& cfg, const SceneView& sv, const PathBuffers& pb, int bounce )
@@ -1416,13 +1653,19 @@ void LaunchTonemap( const LaunchCfg& cfg, const float4* film, float* linearOut, 
 void LaunchTraceClosest( const LaunchCfg& cfg, const SceneView& sv, uint64_t n, const float* origins, const float* dirs, int32_t* prim,
                          float* t, float* u, float* v, uint32_t* nodes, uint32_t* tests )
 {
-    hipLaunchKernelGGL( TraceClosestKernel, dim3( GridFor( cfg, n ) ), dim3( kBlock ), 0, cfg.stream, sv, n, origins, dirs, prim, t, u, v, nodes, tests );
+    if ( cfg.ordered )
+        hipLaunchKernelGGL( TraceClosestKernel< true >, dim3( GridFor( cfg, n ) ), dim3( kBlock ), 0, cfg.stream, sv, n, origins, dirs, prim, t, u, v, nodes, tests );
+    else
+        hipLaunchKernelGGL( TraceClosestKernel< false >, dim3( GridFor( cfg, n ) ), dim3( kBlock ), 0, cfg.stream, sv, n, origins, dirs, prim, t, u, v, nodes, tests );
 }
 
 void LaunchTraceAny( const LaunchCfg& cfg, const SceneView& sv, uint64_t n, const float* origins, const float* dirs, const float* tMax,
                      uint8_t* occluded, uint32_t* nodes, uint32_t* tests )
 {
-    hipLaunchKernelGGL( TraceAnyKernel, dim3( GridFor( cfg, n ) ), dim3( kBlock ), 0, cfg.stream, sv, n, origins, dirs, tMax, occluded, nodes, tests );
+    if ( cfg.ordered )
+        hipLaunchKernelGGL( TraceAnyKernel< true >, dim3( GridFor( cfg, n ) ), dim3( kBlock ), 0, cfg.stream, sv, n, origins, dirs, tMax, occluded, nodes, tests );
+    else
+        hipLaunchKernelGGL( TraceAnyKernel< false >, dim3( GridFor( cfg, n ) ), dim3( kBlock ), 0, cfg.stream, sv, n, origins, dirs, tMax, occluded, nodes, tests );
 }
 
 } // namespace ptd

@@ -57,6 +57,7 @@ struct DevTexture
 struct SceneView
 {
     const float4* nodes;
+    const float4* orderedNodes; // second layout for front-to-back traversal: 4 x float4 per node, or nullptr
     const float4* prims;
     const float4* triShade;
     const float4* spheres;
@@ -67,6 +68,8 @@ struct SceneView
     const float4* skybox; // 6 * w * h texels or nullptr
     uint32_t numNodes;
     uint32_t numTopNodes;
+    uint32_t numOrderedNodes; // records in orderedNodes (nodes + 1: record 1 is padding, so that sibling pairs share a 128-byte line)
+    uint32_t numTopOrdered;   // records at the front of orderedNodes that hold the top of the tree
     uint32_t numPrims;
     uint32_t numSpheres;
     uint32_t numLights;
@@ -115,6 +118,8 @@ struct PathBuffers
     uint32_t* sphereQueue;  // entries whose closest hit is a sphere, shaded by their own kernel instance
     uint32_t* counts;       // [bounce][kCountsPerBounce][unit] queue segment lengths
     uint32_t* cursors;      // [bounce][2] next unit to hand out in ExtendKernel / ConnectKernel
+    uint32_t* redo;         // entries whose front-to-back closest hit was ambiguous, traced again in the reference's order
+    uint32_t* redoCount;    // [bounce] entries in redo
     uint64_t capacity;      // paths in flight; units * kUnitPaths * shadow slots < 2^32
     uint32_t units;         // units of kUnitPaths consecutive path ids in this pass
     uint32_t shadowSlots;   // shadow records per path, at least 1
@@ -134,7 +139,7 @@ enum
 enum
 {
     ST_RAYS_CLOSEST, ST_RAYS_SHADOW, ST_NODES_CLOSEST, ST_NODES_SHADOW, ST_TRI_CLOSEST, ST_TRI_SHADOW,
-    ST_SPH_CLOSEST, ST_SPH_SHADOW, ST_SHADED, ST_STEPS_CLOSEST, ST_STEPS_SHADOW, ST_COUNT
+    ST_SPH_CLOSEST, ST_SPH_SHADOW, ST_SHADED, ST_STEPS_CLOSEST, ST_STEPS_SHADOW, ST_RAYS_REDONE, ST_COUNT
 };
 
 struct LaunchCfg
@@ -143,6 +148,7 @@ struct LaunchCfg
     int blocks;        // grid size of the grid-stride kernels
     int extendBlocks;  // resident blocks of ExtendKernel
     int connectBlocks; // resident blocks of ConnectKernel
+    bool ordered;      // front-to-back traversal over SceneView::orderedNodes
 };
 
 // --- launch wrappers (kernels.hip) ---------------------------------------------------------------------

@@ -75,7 +75,7 @@ class SceneData:
         s.image_width, s.image_height, s.max_depth = desc.image_width, desc.image_height, desc.max_depth
         return s
 
-    def to_desc(self, device=0):
+    def to_desc(self, device=0, flags=0, top_nodes=0):
         """Returns a PtSceneDesc pointing into this object's arrays.  The descriptor keeps the arrays alive
         through an attribute, but the SceneData must not be modified while the descriptor is in use."""
         d = abi.PtSceneDesc()
@@ -109,6 +109,7 @@ class SceneData:
         d.image_width, d.image_height = int(self.image_width), int(self.image_height)
         d.max_depth = int(self.max_depth)
         d.device = int(device)
+        d.flags, d.top_nodes = int(flags), int(top_nodes)
         d._keep = keep
         return d
 

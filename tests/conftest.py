@@ -32,15 +32,17 @@ def have_reference():
     return ref.available()
 
 
-def assert_bits_equal(a, b, what=""):
-    """Bit-exact comparison of float arrays (NaNs compare equal if their payloads do)."""
+def assert_bits_equal(a, b, what="", allow_signed_zero=False):
+    """Bit-exact comparison: float arrays are compared as their bit patterns, so +0 differs from -0 and a NaN
+    equals only a NaN with the same sign and payload.  allow_signed_zero=True lets +0 match -0 (and nothing else)."""
     a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
     assert a.shape == b.shape, f"{what}: shapes {a.shape} vs {b.shape}"
+    assert a.dtype == b.dtype, f"{what}: dtypes {a.dtype} vs {b.dtype}"
     if a.dtype.kind == "f":
-        ia, ib = a.view(np.uint32), b.view(np.uint32)
-        # +0 and -0 differ in bits but not in value; the comparison is on values, NaN == NaN
-        same = (a == b) | (np.isnan(a) & np.isnan(b))
-        _ = ia, ib
+        bits = {2: np.uint16, 4: np.uint32, 8: np.uint64}[a.dtype.itemsize]
+        same = a.view(bits) == b.view(bits)
+        if allow_signed_zero:
+            same |= (a == 0) & (b == 0)
     else:
         same = a == b
     bad = np.argwhere(~same)

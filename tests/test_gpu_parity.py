@@ -318,20 +318,17 @@ def test_leaves_with_several_shapes(name, max_shapes, scenes):
 
 
 @pytest.mark.parametrize("name,keep", [("mixed", 0), ("mixed", 1), ("cornell", 0)])
-def test_single_light_direct_sum_equals_resolve_pass(name, keep, scenes, monkeypatch):
+def test_single_light_direct_sum_equals_resolve_pass(name, keep, scenes):
     """With one light and one sample per hit the shadow-ray kernel adds the direct light itself; with
-    PT_NO_DIRECT_SUM set at upload the separate summation pass runs instead.  Same film, bit for bit, and both
-    match the checker."""
+    PT_SCENE_NO_DIRECT_SUM set at upload the separate summation pass runs instead.  Same film, bit for bit, and
+    both match the checker."""
     scene = scenes[name].with_image(40, 40)
     scene.lights = scene.lights[keep:keep + 1].copy()
     scene.lights["n_samples"] = 1
-    desc = scene.to_desc()
-    want, _ = checker.OracleScene(desc).li_image(8, seed=4)
+    want, _ = checker.OracleScene(scene.to_desc()).li_image(8, seed=4)
     films = []
     for separate_pass in (False, True):
-        if separate_pass:
-            monkeypatch.setenv("PT_NO_DIRECT_SUM", "1")
-        with api.DeviceScene(desc) as dev:
+        with api.DeviceScene(scene.to_desc(flags=abi.PT_SCENE_NO_DIRECT_SUM if separate_pass else 0)) as dev:
             dev.render(8, seed=4)
             lin, _, stats = dev.readback()
             assert stats.rays_shadow > 0
