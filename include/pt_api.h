@@ -327,6 +327,17 @@ int pt_trace_any_mode( PtScene* scene, uint32_t traversal, uint64_t n, const flo
                        const float* t_max, uint8_t* occluded,
                        uint32_t* nodes_visited, uint32_t* prim_tests );
 
+/* pt_trace_closest for callers that cannot allocate device memory (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments and results as
+ * pt_trace_closest, but the rays and results are staged in an array that is part of the library's code object
+ * (12 MiB per GPU, there until the process ends) instead of freshly allocated buffers: the call makes no hipMalloc
+ * or hipFree.  At most PT_TRACE_STATIC_MAX_RAYS rays per call, more is PT_ERR_INVALID_ARG.  All scenes on one GPU
+ * share that GPU's array, so calls that overlap in time on one GPU race; calls on different GPUs do not. */
+#define PT_TRACE_STATIC_MAX_RAYS 262144u
+int pt_trace_closest_static( PtScene* scene, uint64_t n, const float* origins, const float* directions,
+                             int32_t* prim, float* t, float* u, float* v,
+                             uint32_t* nodes_visited, uint32_t* prim_tests );
+
 /* The film of this scene on its GPU: image_width * image_height float4 (sum r, sum g, sum b, sample
  * count), for a host that merges the films of several GPUs with one RCCL reduce.  No counterpart in the
  * reference (it is single-process). */

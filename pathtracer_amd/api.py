@@ -56,6 +56,7 @@ def lib():
         L.pt_trace_closest.argtypes = [C.c_void_p, C.c_uint64] + [C.c_void_p] * 8
         L.pt_trace_any.argtypes = [C.c_void_p, C.c_uint64] + [C.c_void_p] * 6
         L.pt_trace_closest_mode.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64] + [C.c_void_p] * 8
+        L.pt_trace_closest_static.argtypes = [C.c_void_p, C.c_uint64] + [C.c_void_p] * 8
         L.pt_trace_any_mode.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64] + [C.c_void_p] * 6
         L.pt_film_device_ptr.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
         L.pt_clear_film.argtypes = [C.c_void_p]
@@ -167,6 +168,17 @@ class DeviceScene:
         _check(lib().pt_trace_closest_mode(self._h, traversal, n, o.ctypes.data, d.ctypes.data, out["prim"].ctypes.data,
                                            out["t"].ctypes.data, out["u"].ctypes.data, out["v"].ctypes.data,
                                            out["nodes"].ctypes.data, out["prim_tests"].ctypes.data))
+        return out
+
+    def trace_closest_static(self, origins, dirs):
+        """pt_trace_closest_static: the same query without any device allocation (at most abi.PT_TRACE_STATIC_MAX_RAYS rays)."""
+        o, d = _f32(origins).reshape(-1, 3), _f32(dirs).reshape(-1, 3)
+        n = len(o)
+        out = {"prim": np.zeros(n, np.int32), "t": np.zeros(n, np.float32), "u": np.zeros(n, np.float32),
+               "v": np.zeros(n, np.float32), "nodes": np.zeros(n, np.uint32), "prim_tests": np.zeros(n, np.uint32)}
+        _check(lib().pt_trace_closest_static(self._h, n, o.ctypes.data, d.ctypes.data, out["prim"].ctypes.data,
+                                             out["t"].ctypes.data, out["u"].ctypes.data, out["v"].ctypes.data,
+                                             out["nodes"].ctypes.data, out["prim_tests"].ctypes.data))
         return out
 
     def trace_any(self, origins, dirs, t_max, traversal=abi.PT_TRAVERSAL_REFERENCE):

@@ -12,6 +12,7 @@
 #include <cstring>
 #include <exception>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <queue>
 #include <string>
@@ -19,10 +20,38 @@
 
 using namespace ptd;
 
+// Staging memory of pt_trace_closest_static, the entry point that allocates nothing: one array per GPU, part of the
+// library's code object, alive until the process ends.  Per ray: origin and direction (24 bytes) in, primitive, t,
+// u, v and the two counters (24 bytes) out; eight sections of kStaticRays elements each.
+constexpr uint64_t kStaticRays = PT_TRACE_STATIC_MAX_RAYS;
+static __device__ __align__( 256 ) unsigned char scratch[kStaticRays * 48];
+
 namespace
 {
 
 thread_local std::string g_error;
+
+// Device address of `scratch` on every GPU this process has uploaded a scene to.  The array's name is a host-side
+// handle, not an address: only what hipGetSymbolAddress returns, with that GPU current, may go to a kernel or a copy.
+constexpr int kMaxDevices = 64;
+std::mutex g_scratchMutex;
+unsigned char* g_scratchPtr[kMaxDevices] = {};
+
+// Must run with `device` current.  Allocates nothing: the array exists as soon as the code object is loaded.
+hipError_t ScratchAddress( int device, unsigned char** out )
+{
+    if ( device < 0 || device >= kMaxDevices ) return hipErrorInvalidDevice;
+    std::lock_guard< std::mutex > lock( g_scratchMutex );
+    if ( !g_scratchPtr[device] )
+    {
+        void* p = nullptr;
+        const hipError_t e = hipGetSymbolAddress( &p, HIP_SYMBOL( scratch ) );
+        if ( e != hipSuccess ) return e;
+        g_scratchPtr[device] = static_cast< unsigned char* >( p );
+    }
+    *out = g_scratchPtr[device];
+    return hipSuccess;
+}
 
 int Fail( int code, const char* fmt, ... )
 {
@@ -684,6 +713,10 @@ try
     HIP_TRY( hipGetDeviceCount( &deviceCount ) );
     if ( desc->device < 0 || desc->device >= deviceCount ) return Fail( PT_ERR_DEVICE, "device %d requested, %d GPU(s) visible", desc->device, deviceCount );
     HIP_TRY( hipSetDevice( desc->device ) );
+    {
+        unsigned char* staging = nullptr; // set-up for pt_trace_closest_static: this GPU's address of the staging array
+        HIP_TRY( ScratchAddress( desc->device, &staging ) );
+    }
 
     std::unique_ptr< PtScene > owner( new PtScene ); // freed on every early return and if anything below throws
     PtScene* s = owner.get();
@@ -1006,6 +1039,45 @@ int pt_trace_closest( PtScene* s, uint64_t n, const float* origins, const float*
                       uint32_t* nodes_visited, uint32_t* prim_tests )
 {
     return pt_trace_closest_mode( s, PT_TRAVERSAL_REFERENCE, n, origins, directions, prim, t, u, v, nodes_visited, prim_tests );
+}
+
+int pt_trace_closest_static( PtScene* s, uint64_t n, const float* origins, const float* directions, int32_t* prim, float* t, float* u, float* v,
+                             uint32_t* nodes_visited, uint32_t* prim_tests )
+try
+{
+    if ( !s || ( n && ( !origins || !directions ) ) ) return Fail( PT_ERR_INVALID_ARG, "pt_trace_closest_static: null argument" );
+    if ( n > kStaticRays )
+        return Fail( PT_ERR_INVALID_ARG, "pt_trace_closest_static: %llu rays, the staging array holds %llu (PT_TRACE_STATIC_MAX_RAYS); split the batch or use pt_trace_closest",
+                     (unsigned long long)n, (unsigned long long)kStaticRays );
+    if ( n == 0 ) return PT_OK;
+    HIP_TRY( hipSetDevice( s->device ) );
+    unsigned char* base = nullptr;
+    HIP_TRY( ScratchAddress( s->device, &base ) ); // found at pt_upload_scene; a table lookup here
+    float* dO       = reinterpret_cast< float* >( base );
+    float* dD       = reinterpret_cast< float* >( base + kStaticRays * 12 );
+    int32_t* dPrim  = reinterpret_cast< int32_t* >( base + kStaticRays * 24 );
+    float* dT       = reinterpret_cast< float* >( base + kStaticRays * 28 );
+    float* dU       = reinterpret_cast< float* >( base + kStaticRays * 32 );
+    float* dV       = reinterpret_cast< float* >( base + kStaticRays * 36 );
+    uint32_t* dN    = reinterpret_cast< uint32_t* >( base + kStaticRays * 40 );
+    uint32_t* dP    = reinterpret_cast< uint32_t* >( base + kStaticRays * 44 );
+    HIP_TRY( hipMemcpyAsync( dO, origins, n * 12, hipMemcpyHostToDevice, s->stream ) );
+    HIP_TRY( hipMemcpyAsync( dD, directions, n * 12, hipMemcpyHostToDevice, s->stream ) );
+    const LaunchCfg cfg{ s->stream, s->gridBlocks, s->extendBlocks, s->connectBlocks, false };
+    LaunchTraceClosest( cfg, s->view, n, dO, dD, dPrim, dT, dU, dV, dN, dP ); // every output element below n is written
+    HIP_TRY( hipGetLastError() );
+    if ( prim ) HIP_TRY( hipMemcpyAsync( prim, dPrim, n * 4, hipMemcpyDeviceToHost, s->stream ) );
+    if ( t ) HIP_TRY( hipMemcpyAsync( t, dT, n * 4, hipMemcpyDeviceToHost, s->stream ) );
+    if ( u ) HIP_TRY( hipMemcpyAsync( u, dU, n * 4, hipMemcpyDeviceToHost, s->stream ) );
+    if ( v ) HIP_TRY( hipMemcpyAsync( v, dV, n * 4, hipMemcpyDeviceToHost, s->stream ) );
+    if ( nodes_visited ) HIP_TRY( hipMemcpyAsync( nodes_visited, dN, n * 4, hipMemcpyDeviceToHost, s->stream ) );
+    if ( prim_tests ) HIP_TRY( hipMemcpyAsync( prim_tests, dP, n * 4, hipMemcpyDeviceToHost, s->stream ) );
+    HIP_TRY( hipStreamSynchronize( s->stream ) );
+    return PT_OK;
+}
+catch ( ... )
+{
+    return HostFailure( "pt_trace_closest_static" );
 }
 
 int pt_trace_any_mode( PtScene* s, uint32_t traversal, uint64_t n, const float* origins, const float* directions, const float* t_max,
