@@ -46,6 +46,9 @@ def parse():
     p.add_argument("--triangles", type=int, default=262267)
     p.add_argument("--texture-size", type=int, default=1024)
     p.add_argument("--seed", type=int, default=0)
+    p.add_argument("--traversal", choices=("ordered", "reference"), default="ordered",
+                   help="child visiting order of the BVH traversal: front to back (default; same hits and film, fewer node "
+                        "visits) or the reference's first-child-first order (counters equal to the CPU's)")
     p.add_argument("--cpu-baseline-spp", type=int, default=64, help="most samples per pixel the CPU baseline renders (0 = skip)")
     p.add_argument("--cpu-baseline-seconds", type=float, default=20.0, help="CPU time the baseline sample is sized for")
     p.add_argument("--save-image", default="", help="write the tonemapped frame of rank 0 to this file")
@@ -98,7 +101,8 @@ def main():
 
     def run_step(step, profile):
         first = (step * world + rank) * spp_step
-        dev.render(spp_total, first, first + spp_step, seed=args.seed, accumulate=True, profile=profile)
+        dev.render(spp_total, first, first + spp_step, seed=args.seed, accumulate=True, profile=profile,
+                   ordered=args.traversal == "ordered")
 
     dev.clear_film()
     for w in range(args.warmup):

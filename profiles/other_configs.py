@@ -17,23 +17,25 @@ from pathtracer_amd import api, host  # noqa: E402
 from pathtracer_amd.scene import SceneData  # noqa: E402
 
 
-def measure(name, desc, spp, repeats=3):
+def measure(name, desc, spp, repeats=3, ordered=True):
     with api.DeviceScene(desc) as dev:
-        dev.render(min(spp, 2), seed=1)  # warm-up: allocations, code upload
+        dev.render(min(spp, 2), seed=1, ordered=ordered)  # warm-up: allocations, code upload
         dev.readback()
         best = None
         for r in range(repeats):
-            dev.render(spp, seed=r)
+            dev.render(spp, seed=r, ordered=ordered, profile=True)
             _, _, st = dev.readback()
             if best is None or st.render_ms < best.render_ms:
                 best = st
         rays = best.rays_closest + best.rays_shadow
         print(json.dumps({
-            "config": name, "width": desc.image_width, "height": desc.image_height, "depth": desc.max_depth, "spp": spp,
+            "config": name, "traversal": "ordered" if ordered else "reference", "width": desc.image_width, "height": desc.image_height, "depth": desc.max_depth, "spp": spp,
             "triangles": int(desc.num_triangles), "nodes": int(desc.num_nodes),
             "samples": int(best.samples), "rays": int(rays), "render_ms": round(best.render_ms, 3),
             "mrays_per_s": round(rays / best.render_ms * 1e-3, 1),
             "msamples_per_s": round(best.samples / best.render_ms * 1e-3, 1),
+            "extend_ms": round(best.kernel_ms[1], 3), "shade_ms": round(best.kernel_ms[2], 3), "connect_ms": round(best.kernel_ms[3], 3),
+            "rays_redone": int(best.rays_redone),
             "nodes_per_ray": round((best.nodes_closest + best.nodes_shadow) / rays, 2),
             "prim_tests_per_ray": round((best.tri_tests_closest + best.tri_tests_shadow + best.sphere_tests_closest
                                          + best.sphere_tests_shadow) / rays, 3),
@@ -43,22 +45,27 @@ def measure(name, desc, spp, repeats=3):
 def main():
     p = argparse.ArgumentParser()
     p.add_argument("--soup-triangles", type=int, default=20_000_000)
+    p.add_argument("--traversal", choices=("ordered", "reference", "both"), default="both")
     a = p.parse_args()
+    modes = {"ordered": [True], "reference": [False], "both": [False, True]}[a.traversal]
 
     cornell = SceneData.load(os.path.join(ROOT, "tests", "golden", "cornell_scene.npz")).with_image(1024, 1024)
-    measure("cornell 1024^2 (configs[1])", cornell.to_desc(), 256)
+    for m in modes:
+        measure("cornell 1024^2 (configs[1])", cornell.to_desc(), 256, ordered=m)
 
     t = time.time()
     with host.HostScene.knot(seed=2, triangles=871414) as hs:
         hs.set_image(3840, 2160, 3840 / 2160)
         hs.set_max_depth(1)
         print(f"knot scene: {time.time() - t:.1f} s", file=sys.stderr)
-        measure("knot 871k 4K primary + shadow (configs[3])", hs.desc(), 16)
+        for m in modes:
+            measure("knot 871k 4K primary + shadow (configs[3])", hs.desc(), 16, ordered=m)
 
     t = time.time()
     with host.HostScene.soup(seed=3, triangles=a.soup_triangles, edge=0.01, skybox_size=1024) as hs:
         print(f"soup scene: {time.time() - t:.1f} s", file=sys.stderr)
-        measure("soup 4K depth 5 (configs[4])", hs.desc(), 8)
+        for m in modes:
+            measure("soup 4K depth 5 (configs[4])", hs.desc(), 8, ordered=m)
 
 
 if __name__ == "__main__":
