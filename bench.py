@@ -11,16 +11,25 @@ the same triangle count (262,267), camera, light and 24 textured 1024^2 material
 
 One step = one pass of the hot path over one batch: --spp-per-step samples of every pixel (default 128, all in
 flight at once: 265 M paths, 48 GB of path state), i.e. 1920 * 1080 * 128 = 265.4 M pixel samples per GPU and
-step.  Every rank renders its own sample indices of the same frame (weak scaling: per-GPU work per step is
-fixed); after the last step the per-GPU films are summed onto rank 0 with one RCCL reduce, inside the timed
-region.  The default --steps 8 on one GPU is the full 1024 spp frame.
+step.  --scaling weak (default): every rank renders its own --spp-per-step samples per step, per-GPU work per step
+is fixed.  --scaling strong: the frame is fixed - step k is samples [k * S, (k + 1) * S) of the frame, S =
+--spp-per-step, and the ranks share them (pathtracer_amd.path_tracer.sample_range), so --steps 8 is the 1024 spp frame
+of the configuration whatever the number of GPUs.  After the last step the per-GPU films are summed onto rank 0 with
+one RCCL reduce, inside the timed region.  The default --steps 8 on one GPU is the full 1024 spp frame.
 
-The JSON line carries `roofline` for the dominant kernel (closest-hit traversal or shadow-ray traversal,
-whichever took longer): algorithmic bytes from the kernel's own counters (32 B per node fetched, 48 B per
-triangle test, 84 / 16 B per sphere test, 48 / 36 B per ray in + out) over the kernel time measured with HIP
-events on the stream the kernels run on; and `cpu_baseline`: the reference's own compiled hot path
-(oracle/_ref/libptref.so) or, without it, the CPU restatement (oracle/pt_oracle.c), both OpenMP, timed on this
-host over a bounded sample of the same frame.
+The JSON line carries `roofline` for the dominant kernel (closest-hit traversal or shadow-ray traversal, whichever
+took longer).  The scene's 50 MB of nodes and primitive records live in the caches, so the memory system does not
+bound that kernel; the CUs' own units do.  `frac` is therefore the share of the SIMDs' vector issue slots the kernel
+uses (rocprofv3's VALUBusy: SQ_ACTIVE_INST_VALU * 4 / SIMDs / cycles) or the share of time its texture addressers -
+the unit every vector memory instruction passes through - are busy (TA_TA_BUSY / CUs / cycles), whichever is
+higher (`ceilings` lists all three with the memory system), taken from the committed counter summary of this same
+command under profiles/ - only while that summary was collected with the same kernel sources and traversal order;
+otherwise the line says so and falls back to the compulsory bytes.  Beside it, measured live: the kernel's average launch time from HIP events on the
+launch stream, its algorithmic bytes (the reference's per-ray byte model times the kernel's own counters) and,
+under `hbm`, those bytes, the bytes that left the L2 (same summary) and the compulsory bytes (scene records once,
+rays in, hits out) per launch as fractions of the 8 TB/s HBM peak.  `cpu_baseline`: the reference's own compiled
+hot path (oracle/_ref/libptref.so) or, without it, the CPU restatement (oracle/pt_oracle.c), both OpenMP, timed on
+this host over a bounded sample of the same frame, before the GPU's warm-up.
 """
 import argparse
 import glob
@@ -33,6 +42,16 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
+KERNEL_SOURCES = ("pathtracer_amd/csrc/kernels.hip", "pathtracer_amd/csrc/pt_device.h", "pathtracer_amd/csrc/pt_sincosf.h")
+
+
+def kernel_source_hash():
+    """Identifies the kernels a counter summary under profiles/ was collected with."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        h.update(open(os.path.join(ROOT, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def parse():
@@ -52,6 +71,8 @@ def parse():
     p.add_argument("--cpu-baseline-spp", type=int, default=64, help="most samples per pixel the CPU baseline renders (0 = skip)")
     p.add_argument("--cpu-baseline-seconds", type=float, default=20.0, help="CPU time the baseline sample is sized for")
     p.add_argument("--save-image", default="", help="write the tonemapped frame of rank 0 to this file")
+    p.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                   help="weak: --spp-per-step samples per step and GPU; strong: --spp-per-step samples per step shared by the GPUs")
     p.add_argument("--rehearse-on-one-gpu", action="store_true",
                    help="run all ranks on GPU 0 with the gloo backend: a dry run of the multi-process path on a one-GPU box "
                         "(the numbers mean nothing)")
@@ -83,6 +104,9 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
 
+    # tensors of the small collectives: on the GPU for RCCL, in host memory for the gloo rehearsal
+    coll_device = "cpu" if args.rehearse_on_one_gpu else f"cuda:{local_rank}"
+
     def barrier():
         if dist is not None:
             dist.barrier()
@@ -97,12 +121,45 @@ def main():
     setup_s = time.time() - t0
 
     spp_step = args.spp_per_step
-    spp_total = spp_step * world * (args.steps + args.warmup)
+    strong = args.scaling == "strong"
+    spp_total = spp_step * (1 if strong else world) * (args.steps + args.warmup)
+    ordered = args.traversal == "ordered"
 
     def run_step(step, profile):
-        first = (step * world + rank) * spp_step
-        dev.render(spp_total, first, first + spp_step, seed=args.seed, accumulate=True, profile=profile,
-                   ordered=args.traversal == "ordered")
+        if strong:   # this rank's share of the step's samples of the frame
+            begin, end = path_tracer.sample_range(spp_step, rank, world)
+            first, last = step * spp_step + begin, step * spp_step + end
+        else:
+            first = (step * world + rank) * spp_step
+            last = first + spp_step
+        if last > first:
+            dev.render(spp_total, first, last, seed=args.seed, accumulate=True, profile=profile, ordered=ordered)
+
+    # CPU baseline beside the GPU number, rank 0 at N = 1 only, before the GPU's warm-up: the reference's own compiled
+    # Li / BVH / shape code (oracle/_ref/libptref.so, built from /root/reference in the build container) when that
+    # library is here, else this repository's C restatement; on a bounded sample of the same frame sized for ~20 s
+    cpu = None
+    if args.cpu_baseline_spp > 0 and world == 1:
+        from oracle import checker, ref
+        threads = checker.max_threads()
+        if ref.available():
+            cpu_scene, kind, what = ref.RefScene(desc), "reference", "the reference's sources (oracle/Makefile.ref) under oracle/ref_harness.cpp, OpenMP"
+        else:
+            cpu_scene, kind, what = checker.OracleScene(desc), "port", "oracle/pt_oracle.c with OpenMP"
+        t1 = time.perf_counter()
+        _, probe = cpu_scene.li_image(spp_total, 0, 1, seed=args.seed)
+        probe_s = time.perf_counter() - t1
+        n_spp = max(1, min(args.cpu_baseline_spp, int(args.cpu_baseline_seconds / max(probe_s, 1e-3))))
+        t1 = time.perf_counter()
+        _, cstats = cpu_scene.li_image(spp_total, 1, 1 + n_spp, seed=args.seed)
+        cpu_s = time.perf_counter() - t1
+        cpu_rays = cstats["rays_closest"] + cstats["rays_shadow"]
+        cpu_samples = args.width * args.height * n_spp
+        cpu = {"value": round(cpu_rays / cpu_s / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": kind,
+               "msamples_per_s": round(cpu_samples / cpu_s / 1e6, 4), "seconds": round(cpu_s, 2),
+               "sample": f"samples 1..{n_spp} of every pixel of the same {args.width}x{args.height} frame "
+                         f"({cpu_samples} pixel samples, {cpu_rays} rays incl. zero-contribution shadow rays), {what}"}
+        del cpu_scene
 
     dev.clear_film()
     for w in range(args.warmup):
@@ -111,7 +168,7 @@ def main():
     if dist is not None:
         # the collective's first use sets up RCCL's channels and buffers: do that on a scratch tensor of the
         # film's shape, outside the timed region like the warm-up steps
-        scratch = torch.zeros_like(path_tracer.film_tensor(dev, local_rank))
+        scratch = torch.zeros_like(path_tracer.film_tensor(dev, local_rank), device=coll_device)
         dist.reduce(scratch, dst=0, op=dist.ReduceOp.SUM)
         del scratch
 
@@ -125,7 +182,7 @@ def main():
     elapsed = time.perf_counter() - t_start
 
     if dist is not None:
-        t = torch.tensor([elapsed], device=f"cuda:{local_rank}", dtype=torch.float64)
+        t = torch.tensor([elapsed], device=coll_device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -135,7 +192,7 @@ def main():
                 "node_steps_shadow"]
     mine = {c: getattr(stats, c) - getattr(warm, c) for c in counters}   # timed steps only
     if dist is not None:
-        t = torch.tensor([mine[c] for c in counters], device=f"cuda:{local_rank}", dtype=torch.int64)
+        t = torch.tensor([mine[c] for c in counters], device=coll_device, dtype=torch.int64)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         total = dict(zip(counters, [int(x) for x in t.tolist()]))
     else:
@@ -146,43 +203,91 @@ def main():
         # dominant traversal kernel on this rank, timed with HIP events around every launch (PT_RENDER_PROFILE)
         ms = {abi.KERNEL_NAMES[i]: stats.kernel_ms[i] for i in range(abi.PT_K_COUNT)}
         launches = {abi.KERNEL_NAMES[i]: int(stats.launches[i] - warm.launches[i]) for i in range(abi.PT_K_COUNT)}
-        bytes_closest = 32 * mine["nodes_closest"] + 48 * mine["tri_tests_closest"] + 84 * mine["sphere_tests_closest"] + 48 * mine["rays_closest"]
+        # a node visit reads its box and two words (32 B), in the front-to-back order also the ray's link (36 B)
+        node_bytes = 36 if ordered else 32
+        bytes_closest = node_bytes * mine["nodes_closest"] + 48 * mine["tri_tests_closest"] + 84 * mine["sphere_tests_closest"] + 48 * mine["rays_closest"]
         bytes_shadow = 32 * mine["nodes_shadow"] + 48 * mine["tri_tests_shadow"] + 16 * mine["sphere_tests_shadow"] + 36 * mine["rays_shadow"]
+        # records of the scene the kernel reads at least once (device sizes), beside the rays in and the results out
+        scene_bytes = int(desc.num_nodes) * (64 if ordered else 32) + int(desc.num_prims) * 64
         if ms["extend"] >= ms["connect"]:
             kernel, kbytes, kms, klaunch, krays = "ExtendKernel", bytes_closest, ms["extend"], launches["extend"], mine["rays_closest"]
             knodes, ksteps = mine["nodes_closest"], mine["node_steps_closest"]
+            instance = lambda name: name.startswith("ExtendKernel<") and name.rstrip(">").split(",")[-1].strip() == ("true" if ordered else "false")
+            compulsory = scene_bytes * klaunch + 48 * krays
         else:
             kernel, kbytes, kms, klaunch, krays = "ConnectKernel", bytes_shadow, ms["connect"], launches["connect"], mine["rays_shadow"]
             knodes, ksteps = mine["nodes_shadow"], mine["node_steps_shadow"]
-        achieved = kbytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
-        # bytes that left the L2 per launch of that kernel (reads corrected for gfx950, writes as counted), from the
-        # newest committed rocprofv3 --pmc summary of this same command (profiles/collect_pmc.sh); null without one
-        traffic, traffic_source, profiled = None, None, {}
-        summaries = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
-        profiled_workload = (args.spp_per_step, args.width, args.height, args.triangles, args.texture_size) == (128, 1920, 1080, 262267, 1024)
-        if summaries and profiled_workload:   # the committed counters are per launch of the default workload
+            instance = lambda name: name.startswith("ConnectKernel<") and name.rstrip(">").split(",")[-1].strip() == "false"
+            compulsory = (int(desc.num_nodes) * 32 + int(desc.num_prims) * 64) * klaunch + 36 * krays
+        launch_s = kms * 1e-3 / max(1, klaunch)
+        algorithmic_gbs = kbytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+        compulsory_gbs = compulsory / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+
+        # Hardware counters of that kernel from the committed rocprofv3 summary of this same command
+        # (profiles/collect_pmc.sh): used only if it was collected with the same kernel sources, traversal order and
+        # workload, so that a stale summary never sits beside fresh timings.
+        profile, profile_name, why_not = None, None, "no counter summary under profiles/"
+        default_workload = (args.spp_per_step, args.width, args.height, args.triangles, args.texture_size) == (128, 1920, 1080, 262267, 1024)
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")), reverse=True):
             try:
-                summary = json.load(open(summaries[-1]))
-                # the kernels are template instances there ("ExtendKernel<false>"); the workload runs one of each
-                entry = next((v for k, v in sorted(summary.items()) if k.split("<")[0] == kernel), {})
-                if "fabric_read_bytes" in entry:
-                    traffic = round(entry["fabric_read_bytes"] + entry.get("fabric_write_bytes", 0.0))
-                    traffic_source = os.path.relpath(summaries[-1], ROOT)
-                # the other figures of that profile the path is judged on: hit rates, vector issue utilisation, waiting
-                profiled = {k: round(entry[k], 4) for k in ("l1_hit_rate", "l2_hit_rate", "valu_utilization",
-                                                             "wave_time_waiting_on_memory") if k in entry}
+                summary = json.load(open(path))
             except (OSError, ValueError):
-                pass
-        roofline = {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
-                    "bytes_per_launch": round(kbytes / max(1, klaunch)), "avg_launch_ms": round(kms / max(1, klaunch), 4),
-                    "launches": klaunch, "bytes_per_ray": round(kbytes / max(1, krays), 1),
-                    "grays_per_s_in_kernel": round(krays / (kms * 1e-3) / 1e9, 3) if kms > 0 else 0.0,
-                    "nodes_per_ray": round(knodes / max(1, krays), 2),
-                    "lanes_per_node_step": round(knodes / max(1, ksteps), 2), "profiled": profiled,
-                    "note": "algorithmic bytes = the reference's per-ray byte model times the kernel's own counters; "
-                            "`traffic` is what left the L2 (the 29 MB of nodes and primitive records are served from "
-                            "L1 / L2 / Infinity Cache after the first touch), so the fraction can exceed 1"}
+                continue
+            meta = summary.get("_meta", {})
+            if not default_workload:
+                why_not = "the committed counter summaries are of the default workload"
+            elif meta.get("kernel_sources") != kernel_source_hash():
+                why_not = f"{os.path.relpath(path, ROOT)} was collected with other kernel sources"
+            elif meta.get("traversal") != args.traversal:
+                why_not = f"{os.path.relpath(path, ROOT)} was collected with the other traversal order"
+            else:
+                name = next((k for k in sorted(summary) if instance(k)), None)
+                if name and "per_dispatch" in summary[name]:
+                    profile, profile_name, kernel = summary[name], os.path.relpath(path, ROOT), name
+            break
+        hbm = {"peak": HBM_PEAK_GBS, "unit": "GB/s",
+               "algorithmic": round(algorithmic_gbs, 1), "algorithmic_frac": round(algorithmic_gbs / HBM_PEAK_GBS, 4),
+               "compulsory": round(compulsory_gbs, 1), "compulsory_frac": round(compulsory_gbs / HBM_PEAK_GBS, 4),
+               "note": "algorithmic = the reference's per-ray byte model times the kernel's own counters (cache hits included, "
+                       "can exceed the HBM peak); compulsory = scene records once per launch + rays in + results out; "
+                       "fabric = bytes that left the L2 per launch (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, Infinity Cache hits included)"}
+        traffic = None
+        if profile:
+            per = profile["per_dispatch"]
+            traffic = round(profile.get("fabric_read_bytes", 0.0) + profile.get("fabric_write_bytes", 0.0))
+            cycles = per.get("GRBM_GUI_ACTIVE", 0.0) / 8                      # the counter sums the 8 XCDs
+            prof_s = profile.get("trace", {}).get("avg_ns", 0.0) * 1e-9 or launch_s
+            busy = per.get("SQ_ACTIVE_INST_VALU", 0.0) * 4                    # SIMD cycles spent issuing vector instructions
+            hbm.update({"fabric": round(traffic / prof_s / 1e9, 1), "fabric_frac": round(traffic / prof_s / 1e9 / HBM_PEAK_GBS, 4)})
+            # Three ceilings, each as busy cycles of the unit over the cycles it had: the SIMDs' vector issue (1,024
+            # SIMDs; rocprofv3's VALUBusy), the texture addressers through which every vector memory instruction
+            # passes (one per CU; TA_TA_BUSY), and the memory system behind the L2 (bytes against the HBM peak).
+            ta_busy = per.get("TA_TA_BUSY_sum", 0.0)
+            ceilings = {"valu_issue": (busy, 1024 * cycles), "texture_addresser": (ta_busy, 256 * cycles)}
+            fracs = {k: round(a / b, 4) if b else 0.0 for k, (a, b) in ceilings.items()}
+            fracs["hbm"] = hbm["fabric_frac"]
+            bound = max(fracs, key=fracs.get)
+            if bound == "hbm":
+                roofline = {"bound": "hbm", "kernel": kernel, "achieved": hbm["fabric"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fracs["hbm"]}
+            else:
+                a, b = ceilings[bound]
+                roofline = {"bound": bound, "kernel": kernel, "achieved": round(a / prof_s / 1e9, 1), "peak": round(b / prof_s / 1e9, 1),
+                            "unit": "G busy cycles/s of the unit, chip-wide", "frac": fracs[bound]}
+            roofline["ceilings"] = fracs
+            roofline.update({"counters_from": profile_name, "counters_kernel_sources": kernel_source_hash(),
+                             "counters_avg_launch_ms": round(prof_s * 1e3, 4),
+                             "counters": {k: round(profile[k], 4) for k in ("l1_hit_rate", "l2_hit_rate", "wave_time_waiting_on_memory",
+                                                                             "wave_time_issue_stalled") if k in profile}})
+        else:
+            # without matching counters only the compulsory bytes are known to have moved
+            roofline = {"bound": "hbm", "kernel": kernel, "achieved": round(compulsory_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(compulsory_gbs / HBM_PEAK_GBS, 4), "counters_from": None, "counters_missing_because": why_not}
+        roofline.update({"traffic": traffic, "hbm": hbm, "traversal": args.traversal,
+                         "bytes_per_launch": round(kbytes / max(1, klaunch)), "avg_launch_ms": round(kms / max(1, klaunch), 4),
+                         "launches": klaunch, "bytes_per_ray": round(kbytes / max(1, krays), 1),
+                         "grays_per_s_in_kernel": round(krays / (kms * 1e-3) / 1e9, 3) if kms > 0 else 0.0,
+                         "nodes_per_ray": round(knodes / max(1, krays), 2),
+                         "lanes_per_node_step": round(knodes / max(1, ksteps), 2)})
 
         # what a plain device-to-device copy reaches on this GPU (read + write bytes), beside the nominal peak
         if world == 1:
@@ -195,33 +300,8 @@ def main():
             for _ in range(10):
                 dst.copy_(src)
             torch.cuda.synchronize(local_rank)
-            roofline["copy_measured_gbs"] = round(10 * 2 * n / (time.perf_counter() - t1) / 1e9, 1)
+            hbm["copy_measured"] = round(10 * 2 * n / (time.perf_counter() - t1) / 1e9, 1)
             del src, dst
-
-        # CPU baseline beside the GPU number, rank 0 at N = 1 only: the reference's own compiled Li / BVH / shape code
-        # (oracle/_ref/libptref.so, built from /root/reference in the build container) when that library is here,
-        # else this repository's C restatement; on a bounded sample of the same frame sized for ~20 s of CPU work
-        cpu = None
-        if args.cpu_baseline_spp > 0 and world == 1:
-            from oracle import checker, ref
-            threads = checker.max_threads()
-            if ref.available():
-                cpu_scene, kind, what = ref.RefScene(desc), "reference", "the reference's sources (oracle/Makefile.ref) under oracle/ref_harness.cpp, OpenMP"
-            else:
-                cpu_scene, kind, what = checker.OracleScene(desc), "port", "oracle/pt_oracle.c with OpenMP"
-            t1 = time.perf_counter()
-            _, probe = cpu_scene.li_image(spp_total, 0, 1, seed=args.seed)
-            probe_s = time.perf_counter() - t1
-            n_spp = max(1, min(args.cpu_baseline_spp, int(args.cpu_baseline_seconds / max(probe_s, 1e-3))))
-            t1 = time.perf_counter()
-            _, cstats = cpu_scene.li_image(spp_total, 1, 1 + n_spp, seed=args.seed)
-            cpu_s = time.perf_counter() - t1
-            cpu_rays = cstats["rays_closest"] + cstats["rays_shadow"]
-            cpu_samples = args.width * args.height * n_spp
-            cpu = {"value": round(cpu_rays / cpu_s / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": kind,
-                   "msamples_per_s": round(cpu_samples / cpu_s / 1e6, 4), "seconds": round(cpu_s, 2),
-                   "sample": f"samples 1..{n_spp} of every pixel of the same {args.width}x{args.height} frame "
-                             f"({cpu_samples} pixel samples, {cpu_rays} rays incl. zero-contribution shadow rays), {what}"}
 
         if args.save_image:
             _, tm, _ = dev.readback(abi.PT_TONEMAP_UNCHARTED2, linear=False)
@@ -234,12 +314,14 @@ def main():
             "msamples_per_s": round(total["samples"] / elapsed / 1e6, 3),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed * 1e3 / args.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"sponza.json stand-in (procedural atrium, {args.triangles} triangles, 24 textured materials "
                                    f"{args.texture_size}^2, camera/light of resources/scenes/sponza.json) {args.width}x{args.height}, "
-                                   f"depth 5, {spp_step} spp per step and GPU",
-                       "spp_rendered": spp_step * world * args.steps, "sample_split": f"{world} x {spp_step} spp per step",
+                                   f"depth 5, {spp_step} spp per step" + (" shared by the GPUs" if strong else " and GPU"),
+                       "traversal": args.traversal,
+                       "spp_rendered": spp_step * (1 if strong else world) * args.steps,
+                       "sample_split": f"{spp_step} spp per step over {world} GPU(s)" if strong else f"{world} x {spp_step} spp per step",
                        "rays_per_sample": round(rays / max(1, total["samples"]), 3),
                        "nodes_per_ray": round((total["nodes_closest"] + total["nodes_shadow"]) / max(1, rays), 2),
                        "tri_tests_per_ray": round((total["tri_tests_closest"] + total["tri_tests_shadow"]) / max(1, rays), 3)},

@@ -343,6 +343,12 @@ int pt_trace_closest_static( PtScene* scene, uint64_t n, const float* origins, c
  * reference (it is single-process). */
 int pt_film_device_ptr( PtScene* scene, void** device_ptr, uint64_t* bytes );
 
+/* Adds the films of `sources`, in the order given, to the film of `dst`, on dst's GPU: one host process that drives
+ * several GPUs (one scene each) sums their films without staging them in host memory.  A source on another GPU is
+ * read in place over xGMI (peer access; copied GPU to GPU first where the GPUs cannot map each other's memory).
+ * The sources are left as they are.  No counterpart in the reference (it is single-process, single-device). */
+int pt_merge_films( PtScene* dst, PtScene* const* sources, uint32_t num_sources );
+
 /* Clears the film and the counters. */
 int pt_clear_film( PtScene* scene );
 

@@ -62,6 +62,7 @@ def lib():
         L.pt_clear_film.argtypes = [C.c_void_p]
         L.pt_download_film.argtypes = [C.c_void_p, C.c_void_p]
         L.pt_upload_film.argtypes = [C.c_void_p, C.c_void_p]
+        L.pt_merge_films.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_uint32]
         L.pt_destroy_scene.argtypes = [C.c_void_p]
         _LIB = L
     return _LIB
@@ -154,6 +155,11 @@ class DeviceScene:
         if film.shape != (self.height, self.width, 4):
             raise ValueError(f"film must be ({self.height}, {self.width}, 4)")
         _check(lib().pt_upload_film(self._h, film.ctypes.data))
+
+    def merge_films(self, others):
+        """Adds the films of the other DeviceScenes (same image size, any GPU) to this one's, on this one's GPU."""
+        handles = (C.c_void_p * len(others))(*[o._h for o in others])
+        _check(lib().pt_merge_films(self._h, handles, len(others)))
 
     def film_device_ptr(self):
         ptr, nbytes = C.c_void_p(), C.c_uint64()

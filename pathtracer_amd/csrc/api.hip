@@ -970,6 +970,56 @@ catch ( ... )
     return HostFailure( "pt_film_device_ptr" );
 }
 
+int pt_merge_films( PtScene* dst, PtScene* const* sources, uint32_t num_sources )
+try
+{
+    if ( !dst || ( num_sources && !sources ) ) return Fail( PT_ERR_INVALID_ARG, "pt_merge_films: null argument" );
+    for ( uint32_t i = 0; i < num_sources; ++i )
+    {
+        const PtScene* src = sources[i];
+        if ( !src || src == dst ) return Fail( PT_ERR_INVALID_ARG, "pt_merge_films: source %u is null or the destination itself", i );
+        if ( src->width != dst->width || src->height != dst->height ) return Fail( PT_ERR_INVALID_ARG, "pt_merge_films: source %u is %d x %d, the destination %d x %d", i, src->width, src->height, dst->width, dst->height );
+    }
+    const LaunchCfg cfg{ dst->stream, dst->gridBlocks, dst->extendBlocks, dst->connectBlocks, false };
+    const uint32_t pixels = static_cast< uint32_t >( dst->width ) * static_cast< uint32_t >( dst->height );
+    DeviceBuffer staging; // only for a source GPU whose memory this GPU cannot map
+    for ( uint32_t i = 0; i < num_sources; ++i ) // in the order given: the sum does not depend on timing
+    {
+        PtScene* src = sources[i];
+        HIP_TRY( hipSetDevice( src->device ) );
+        HIP_TRY( hipStreamSynchronize( src->stream ) ); // its film is complete
+        HIP_TRY( hipSetDevice( dst->device ) );
+        const float4* other = src->film.As< float4 >();
+        if ( src->device != dst->device )
+        {
+            int mappable = 0;
+            HIP_TRY( hipDeviceCanAccessPeer( &mappable, dst->device, src->device ) );
+            if ( mappable )
+            {
+                const hipError_t e = hipDeviceEnablePeerAccess( src->device, 0 );
+                if ( e == hipErrorPeerAccessAlreadyEnabled ) (void)hipGetLastError();
+                else if ( e != hipSuccess ) mappable = 0;
+            }
+            if ( !mappable )
+            {
+                if ( !staging.ptr ) HIP_TRY( staging.Allocate( dst->film.bytes ) );
+                HIP_TRY( hipMemcpyPeerAsync( staging.ptr, dst->device, src->film.ptr, src->device, dst->film.bytes, dst->stream ) );
+                other = staging.As< float4 >();
+            }
+        }
+        LaunchAddFilm( cfg, dst->film.As< float4 >(), other, pixels );
+        HIP_TRY( hipGetLastError() );
+        if ( other == staging.As< float4 >() ) HIP_TRY( hipStreamSynchronize( dst->stream ) ); // before the next source overwrites it
+    }
+    HIP_TRY( hipStreamSynchronize( dst->stream ) );
+    dst->rendered = true;
+    return PT_OK;
+}
+catch ( ... )
+{
+    return HostFailure( "pt_merge_films" );
+}
+
 int pt_download_film( PtScene* s, float* film_rgba )
 try
 {

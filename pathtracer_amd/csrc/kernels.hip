@@ -1476,6 +1476,17 @@ __global__ __launch_bounds__( kBlock ) void FilmKernel( PathBuffers pb, float4* 
     }
 }
 
+// film += other, element by element: the films of several GPUs (or of several scenes on one GPU) summed onto one.
+// `other` may be memory of another GPU mapped for peer access, read over xGMI.
+__global__ __launch_bounds__( kBlock ) void AddFilmKernel( float4* film, const float4* other, uint32_t numPixels )
+{
+    for ( uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < numPixels; i += gridDim.x * kBlock )
+    {
+        const float4 a = film[i], b = other[i];
+        film[i] = make_float4( a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w );
+    }
+}
+
 // Uncharted2TonemapHelper (src/tonemap.cpp:36-45)
 __device__ __forceinline__ float U2Helper( float x )
 {
@@ -1642,6 +1653,11 @@ void LaunchFilm( const LaunchCfg& cfg, const PathBuffers& pb, float4* film, uint
 {
     hipLaunchKernelGGL( FilmKernel, dim3( GridFor( cfg, static_cast< uint64_t >( width ) * height ) ), dim3( kBlock ), 0, cfg.stream, pb, film, width,
                         height, samplesInPass );
+}
+
+void LaunchAddFilm( const LaunchCfg& cfg, float4* film, const float4* other, uint32_t numPixels )
+{
+    hipLaunchKernelGGL( AddFilmKernel, dim3( GridFor( cfg, numPixels ) ), dim3( kBlock ), 0, cfg.stream, film, other, numPixels );
 }
 
 void LaunchTonemap( const LaunchCfg& cfg, const float4* film, float* linearOut, float* tonemappedOut, uint32_t numPixels, float exposure,

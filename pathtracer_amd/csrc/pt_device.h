@@ -162,6 +162,7 @@ void LaunchShade( const LaunchCfg& cfg, const SceneView& sv, const RngParams& rn
 void LaunchConnect( const LaunchCfg& cfg, const SceneView& sv, const PathBuffers& pb, int bounce, uint64_t* stats );
 void LaunchResolve( const LaunchCfg& cfg, const SceneView& sv, const PathBuffers& pb, int bounce );
 void LaunchFilm( const LaunchCfg& cfg, const PathBuffers& pb, float4* film, uint32_t width, uint32_t height, uint32_t samplesInPass );
+void LaunchAddFilm( const LaunchCfg& cfg, float4* film, const float4* other, uint32_t numPixels );
 void LaunchTonemap( const LaunchCfg& cfg, const float4* film, float* linearOut, float* tonemappedOut, uint32_t numPixels,
                     float exposure, float gamma, uint32_t op );
 void LaunchTraceClosest( const LaunchCfg& cfg, const SceneView& sv, uint64_t n, const float* origins, const float* dirs,

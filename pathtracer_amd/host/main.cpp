@@ -32,7 +32,7 @@ struct Options
     std::string sceneFile, resourceDir, output, generate;
     int width = 0, height = 0, depth = -1, spp = 0, device = 0, triangles = 0;
     uint64_t seed = 0;
-    bool haveSeed = false, stats = false, hostTonemap = false;
+    bool haveSeed = false, stats = false, hostTonemap = false, referenceOrder = false;
     std::vector< int > devices; // --devices: the GPUs that share a render; empty = the one of --device
 };
 
@@ -54,6 +54,8 @@ void Help()
                  "  --output FILE        override OutputImageFilename\n"
                  "  --generate atrium|knot|soup [--triangles N]   procedural scene instead of SCENE_FILE\n"
                  "  --stats              print ray and traversal counters after each render\n"
+                 "  --reference-order    visit the BVH in the reference's first-child-first order instead of front to back:\n"
+                 "                       same picture, traversal counters equal to the CPU path's, slower on large scenes\n"
                  "  --host-tonemap       run the tonemap pass on the host with the C library's powf, as the reference\n"
                  "                       does (the saved picture is then the CPU path's to the last bit for equal samples)\n";
 }
@@ -106,6 +108,8 @@ bool ParseArgs( int argc, char** argv, Options& o )
             o.generate = v;
         else if ( a == "--host-tonemap" )
             o.hostTonemap = true;
+        else if ( a == "--reference-order" )
+            o.referenceOrder = true;
         else if ( a == "--seed" && ( v = value() ) )
         {
             o.seed     = std::strtoull( v, nullptr, 0 );
@@ -130,14 +134,14 @@ std::string DefaultResourceDir( const std::string& sceneFile )
 // PathTracer of src/path_tracer.hpp:9-19 on the C-ABI: Render fills renderedImage, SaveImage writes it.  With
 // several GPUs (one uploaded copy of the scene each) every GPU renders a contiguous share of the samples of every
 // pixel from its own host thread - the shares differ by at most one sample, earlier GPUs take the larger ones -
-// and the films (sums per pixel) are added in GPU order on the host and put back on the first GPU, which
-// tonemaps.  The Philox streams are keyed by the absolute sample index, so the picture does not depend on the
+// and the films (sums per pixel) are added in GPU order on the first GPU (pt_merge_films: the other GPUs' films are
+// read in place over xGMI), which tonemaps.  The Philox streams are keyed by the absolute sample index, so the picture does not depend on the
 // number of GPUs beyond the order of the float additions.
 class PathTracer
 {
 public:
-    PathTracer( const std::vector< PtScene* >& gpuScenes, int width, int height, const PtCamera& camera, bool hostTonemap )
-        : m_scenes( gpuScenes ), m_width( width ), m_height( height ), m_camera( camera ), m_hostTonemap( hostTonemap )
+    PathTracer( const std::vector< PtScene* >& gpuScenes, int width, int height, const PtCamera& camera, bool hostTonemap, bool ordered )
+        : m_scenes( gpuScenes ), m_width( width ), m_height( height ), m_camera( camera ), m_hostTonemap( hostTonemap ), m_ordered( ordered )
     {
     }
 
@@ -154,6 +158,7 @@ public:
             const int base = samplesPerPixel / gpus, extra = samplesPerPixel % gpus;
             PtRenderParams params{};
             params.struct_size  = sizeof( params );
+            params.flags        = m_ordered ? PT_RENDER_ORDERED : 0u;
             params.spp_total    = samplesPerPixel;
             params.sample_begin = g * base + std::min( g, extra );
             params.sample_end   = params.sample_begin + base + ( g < extra ? 1 : 0 );
@@ -175,18 +180,18 @@ public:
         PtStats total{};
         if ( gpus > 1 )
         {
-            const size_t floats = static_cast< size_t >( m_width ) * m_height * 4;
-            std::vector< float > sum( floats ), film( floats );
-            if ( pt_download_film( m_scenes[0], sum.data() ) != PT_OK ) return false;
+            // the films are summed on the first GPU, the others' read in place over xGMI, in GPU order
+            if ( pt_merge_films( m_scenes[0], m_scenes.data() + 1, static_cast< uint32_t >( gpus - 1 ) ) != PT_OK )
+            {
+                std::cout << "merging the films: " << pt_last_error() << std::endl;
+                return false;
+            }
             for ( int g = 1; g < gpus; ++g )
             {
-                if ( pt_download_film( m_scenes[g], film.data() ) != PT_OK ) return false;
-                for ( size_t i = 0; i < floats; ++i ) sum[i] += film[i];
                 PtStats one{};
                 if ( pt_readback( m_scenes[g], PT_TONEMAP_NONE, nullptr, nullptr, &one ) != PT_OK ) return false;
                 Add( total, one );
             }
-            if ( pt_upload_film( m_scenes[0], sum.data() ) != PT_OK ) return false;
         }
         // the image holds the tonemapped picture, like Image::m_pixels after src/path_tracer.cpp:211-219
         PtStats first{};
@@ -223,7 +228,7 @@ private:
     std::vector< PtScene* > m_scenes;
     int m_width, m_height;
     PtCamera m_camera;
-    bool m_hostTonemap;
+    bool m_hostTonemap, m_ordered;
 };
 
 } // namespace
@@ -309,7 +314,7 @@ int main( int argc, char** argv )
     // Perform all the renderings ("SamplesPerPixel": [ 8, 32, ... ]), src/main.cpp:30-49
     for ( size_t it = 0; it < sppList.size(); ++it )
     {
-        PathTracer pathTracer( gpuScenes, desc.image_width, desc.image_height, desc.camera, opt.hostTonemap );
+        PathTracer pathTracer( gpuScenes, desc.image_width, desc.image_height, desc.camera, opt.hostTonemap, !opt.referenceOrder );
         PtStats stats{};
         const uint64_t seed = opt.haveSeed ? opt.seed : ( static_cast< uint64_t >( entropy() ) << 32 | entropy() );
         if ( !pathTracer.Render( sppList[it], seed, &stats ) )

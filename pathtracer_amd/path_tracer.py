@@ -65,10 +65,11 @@ def sample_range(spp, rank, world_size):
 
 
 class PathTracer:
-    def __init__(self, device=0, seed=0, tonemap=abi.PT_TONEMAP_UNCHARTED2):
+    def __init__(self, device=0, seed=0, tonemap=abi.PT_TONEMAP_UNCHARTED2, ordered=True):
         self.device = device
         self.seed = seed
         self.tonemap = tonemap
+        self.ordered = ordered      # front-to-back traversal: same picture, fewer node visits
         self.renderedImage = None   # tonemapped, what the reference keeps (src/path_tracer.cpp:210-221)
         self.linearImage = None     # the image before the tonemap pass, which the reference overwrites
         self.stats = None
@@ -91,7 +92,7 @@ class PathTracer:
         except ImportError:
             pass
         begin, end = sample_range(spp, rank, world)
-        dev.render(spp, begin, end, seed=self.seed)
+        dev.render(spp, begin, end, seed=self.seed, ordered=self.ordered)
         if world > 1:
             reduce_film(dev, self.device, dist, process_group)
             if rank != 0:
@@ -123,8 +124,16 @@ def film_tensor(dev, device_index):
 
 
 def reduce_film(dev, device_index, dist, process_group=None):
-    """Sum of the per-GPU films (sum r, g, b and sample count per pixel) onto rank 0: one collective."""
-    film = film_tensor(dev, device_index)
-    dist.reduce(film, dst=0, op=dist.ReduceOp.SUM, group=process_group)
+    """Sum of the per-GPU films (sum r, g, b and sample count per pixel) onto rank 0: one collective.  With the nccl
+    backend that is one RCCL reduce on the device buffers over xGMI.  The gloo backend (rehearsals of the
+    multi-process path on a machine with one GPU, tests) reduces host tensors, so the film goes through host memory."""
     import torch
+    film = film_tensor(dev, device_index)
+    if dist.get_backend(process_group) == "gloo":
+        staged = film.cpu()
+        dist.reduce(staged, dst=0, op=dist.ReduceOp.SUM, group=process_group)
+        if dist.get_rank(process_group) == 0:
+            film.copy_(staged)
+    else:
+        dist.reduce(film, dst=0, op=dist.ReduceOp.SUM, group=process_group)
     torch.cuda.synchronize(device_index)

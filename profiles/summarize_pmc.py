@@ -11,6 +11,7 @@ import csv, glob, json, os, sys
 from collections import defaultdict
 
 root = sys.argv[1]
+traversal = sys.argv[2] if len(sys.argv) > 2 else None
 
 
 def short(name):
@@ -24,7 +25,7 @@ for f in glob.glob(os.path.join(root, "*", "**", "*counter_collection.csv"), rec
     for r in csv.DictReader(open(f)):
         k, c = short(r["Kernel_Name"]), r["Counter_Name"]
         tot[k][c] += float(r["Counter_Value"])
-        disp[k][c].add(r["Dispatch_Id"])
+        disp[k][c].add((f, r["Dispatch_Id"]))   # a counter collected in two passes is averaged over both
 
 out = {}
 for k in sorted(tot):
@@ -41,6 +42,8 @@ for k in sorted(tot):
         d["l2_hit_rate"] = 1 - per.get("TCC_MISS_sum", 0) / per["TCC_REQ_sum"]
     if "SQ_ACTIVE_INST_VALU" in per and per.get("GRBM_GUI_ACTIVE", 0) > 0:
         d["valu_utilization"] = per["SQ_ACTIVE_INST_VALU"] * 4 / (per["GRBM_GUI_ACTIVE"] / 8) / 1024
+    if "TA_TA_BUSY_sum" in per and per.get("GRBM_GUI_ACTIVE", 0) > 0:
+        d["ta_busy"] = per["TA_TA_BUSY_sum"] / 256 / (per["GRBM_GUI_ACTIVE"] / 8)   # mean over the 256 texture addressers
     if "SQ_WAVE_CYCLES" in per and per["SQ_WAVE_CYCLES"] > 0:
         d["wave_time_waiting_on_memory"] = per.get("SQ_WAIT_ANY", 0) / per["SQ_WAVE_CYCLES"]
         d["wave_time_issue_stalled"] = per.get("SQ_WAIT_INST_ANY", 0) / per["SQ_WAVE_CYCLES"]
@@ -52,8 +55,19 @@ for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_stats.csv"), recur
         out.setdefault(k, {})["trace"] = {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]), "total_ns": float(r["TotalDurationNs"]),
                                           "percent": float(r["Percentage"])}
 
+# what the counters belong to: bench.py uses a summary only beside the kernels it was collected with
+import hashlib
+repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+h = hashlib.sha256()
+for f in ("pathtracer_amd/csrc/kernels.hip", "pathtracer_amd/csrc/pt_device.h", "pathtracer_amd/csrc/pt_sincosf.h"):
+    h.update(open(os.path.join(repo, f), "rb").read())
+out["_meta"] = {"kernel_sources": h.hexdigest()[:16], "traversal": traversal}
+
 json.dump(out, open(os.path.join(root, "pmc_summary.json"), "w"), indent=1, sort_keys=True)
 for k, d in out.items():
+    if k == "_meta":
+        print(k, d)
+        continue
     print(k, {x: (round(v, 4) if isinstance(v, float) else v) for x, v in d.items() if x != "per_dispatch"})
     for c, v in sorted(d.get("per_dispatch", {}).items()):
         print(f"    {c:36s} {v:.6g}")
