@@ -142,17 +142,46 @@ def test_split_ranges_and_passes_are_bit_identical(device_scenes):
 
 
 def test_tonemap_matches_reference_vectors(device_scenes, golden):
-    """Film -> Uncharted2 / Reinhard -> gamma -> clamp against the oracle's tonemap of the same linear image."""
+    """Film -> Uncharted2 / Reinhard -> gamma -> clamp against the checker's tonemap of the same linear image (the
+    host C library's powf): bit for bit."""
     scene, dev, _ = device_scenes["cornell"]
     dev.render(4, seed=1)
     lin, tm, _ = dev.readback(abi.PT_TONEMAP_UNCHARTED2)
     want = checker.tonemap(lin, float(scene.camera["exposure"]), float(scene.camera["gamma"]), abi.PT_TONEMAP_UNCHARTED2)
-    assert np.abs(tm - want).max() <= 1e-6
+    assert tm.tobytes() == want.tobytes()
     _, tm, _ = dev.readback(abi.PT_TONEMAP_REINHARD)
     want = checker.tonemap(lin, float(scene.camera["exposure"]), float(scene.camera["gamma"]), abi.PT_TONEMAP_REINHARD)
-    assert np.abs(tm - want).max() <= 1e-6
+    assert tm.tobytes() == want.tobytes()
     _, tm, _ = dev.readback(abi.PT_TONEMAP_NONE)
     assert_bits_equal(tm, lin, "no tonemap")
+
+
+@pytest.mark.parametrize("gamma,exposure", [(2.2, 1.0), (1.8, 0.7), (2.4, 3.0), (1.0, 1.0), (0.45, 2.0)])
+def test_tonemap_is_bit_exact_on_a_film_of_arbitrary_radiance(gamma, exposure, scenes):
+    """614,400 radiance values written into the film (pt_upload_film, one sample per pixel, so the mean is the
+    value itself): dense in [0, 1.25], up to 1e4, zeros and subnormals.  Both operators must give the floats of
+    the C library's powf path (the checker, and the host library's pth_tonemap), including the arguments where a
+    correctly rounded pow differs from powf."""
+    scene = scenes["cornell"].with_image(512, 400)
+    scene.camera = dict(scene.camera, gamma=np.float32(gamma), exposure=np.float32(exposure))
+    rng = np.random.default_rng(int(gamma * 100))
+    n = 512 * 400 * 3
+    values = rng.uniform(0, 1.25, n).astype(np.float32)
+    values[: n // 4] = (rng.uniform(0, 1, n // 4) ** 4 * 1e4).astype(np.float32)
+    values[n // 4: n // 4 + 1000] = np.float32(0)
+    values[n // 4 + 1000: n // 4 + 2000] = (rng.integers(1, 1 << 23, 1000).astype(np.uint32)).view(np.float32)   # subnormals
+    values[n // 4 + 2000: n // 4 + 3000] = rng.uniform(0, 1e-30, 1000).astype(np.float32)
+    rng.shuffle(values)
+    film = np.concatenate([values.reshape(400, 512, 3), np.ones((400, 512, 1), np.float32)], axis=2)
+    with api.DeviceScene(scene.to_desc()) as dev:
+        dev.upload_film(film)
+        for op in (abi.PT_TONEMAP_UNCHARTED2, abi.PT_TONEMAP_REINHARD):
+            lin, tm, _ = dev.readback(op)
+            assert lin.tobytes() == values.tobytes()
+            want = checker.tonemap(lin, float(exposure), float(gamma), op)
+            differing = int((tm.view(np.uint32) != want.view(np.uint32)).sum())
+            assert differing == 0, f"operator {op}: {differing} of {n} values differ from the C library's"
+            assert tm.tobytes() == host.tonemap(lin, float(exposure), float(gamma), op).tobytes()
 
 
 def test_depth_limits_and_empty_inputs(scenes):

@@ -1,0 +1,62 @@
+"""pathtracer_amd/csrc/pt_powf.h - the C library's powf restated for the tonemap kernel - compiled for the host and
+compared with the host's own powf: every bit pattern of the result, over the tonemap's domain (every 37th float of
+[0, 1.25] for eight gammas), random bit patterns (all special cases among them), moderate ranges and negative
+bases with integer exponents.  The host must have FMA: the header fuses the multiply-adds like glibc's variant
+for such hosts does."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+HARNESS = r'''
+#include <cmath>
+#include <cstdio>
+#include <cstdint>
+#include <cstring>
+#include <random>
+#include "pt_powf.h"
+static uint32_t bits( float f ) { uint32_t u; memcpy( &u, &f, 4 ); return u; }
+static float fromBits( uint32_t u ) { float f; memcpy( &f, &u, 4 ); return f; }
+int main()
+{
+    unsigned long long n = 0, bad = 0;
+    auto check = [&]( float x, float y ) {
+        volatile float xv = x, yv = y;
+        float a = ptd::PowLibm( x, y ), b = powf( xv, yv );
+        n++;
+        if ( !( bits( a ) == bits( b ) || ( std::isnan( a ) && std::isnan( b ) ) ) )
+        {
+            if ( bad < 10 ) printf( "x=%a y=%a restated=%a libm=%a\n", x, y, a, b );
+            bad++;
+        }
+    };
+    std::mt19937_64 rng( 1 );
+    const float gammas[] = { 1.0f, 1.8f, 2.0f, 2.2f, 2.4f, 2.6f, 3.0f, 0.45f };
+    for ( float g : gammas )
+        for ( uint32_t u = 0; u <= bits( 1.25f ); u += 37 ) check( fromBits( u ), 1.0f / g );
+    for ( int i = 0; i < 4000000; i++ ) { uint64_t r = rng(); check( fromBits( (uint32_t)r ), fromBits( (uint32_t)( r >> 32 ) ) ); }
+    std::uniform_real_distribution< float > ux( 0.0f, 100.0f ), uy( -20.0f, 20.0f );
+    for ( int i = 0; i < 4000000; i++ ) check( ux( rng ), uy( rng ) );
+    for ( int i = 0; i < 1000000; i++ ) check( -ux( rng ), (float)(int)uy( rng ) );
+    const float sp[] = { 0.0f, -0.0f, 1.0f, -1.0f, 2.0f, -2.0f, 0.5f, -0.5f, INFINITY, -INFINITY, NAN, 1e-40f, -1e-40f, 3.0f, -3.0f, 1e38f,
+                         1e-38f, 127.0f, 128.0f, -149.0f, -150.0f, 1.5f, -1.5f, 16777216.0f, 16777217.0f, 33554432.0f };
+    for ( float a : sp ) for ( float b : sp ) check( a, b );
+    printf( "%llu cases, %llu differ\n", n, bad );
+    return bad ? 1 : 0;
+}
+'''
+
+
+def test_restated_powf_equals_the_host_library(tmp_path):
+    if "fma" not in open("/proc/cpuinfo").read():
+        pytest.skip("host without FMA: its C library runs the variant with separate multiplies and adds")
+    src = tmp_path / "powf_check.cpp"
+    src.write_text(HARNESS)
+    exe = tmp_path / "powf_check"
+    subprocess.run(["g++", "-O2", "-mfma", "-ffp-contract=off", "-I", os.path.join(ROOT, "pathtracer_amd", "csrc"), str(src), "-o", str(exe)], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    print(r.stdout)
+    assert r.returncode == 0, r.stdout
+    assert int(r.stdout.split()[-2]) == 0 and int(r.stdout.split()[-4]) > 2.3e8
