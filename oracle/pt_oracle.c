@@ -406,9 +406,18 @@ static int bvh_intersect_ordered( const PtSceneDesc* d, v3 o, v3 dir, Hit* hit, 
     }
     if ( ambiguous )
     {
-        *hit = start;
+        /* the reference's order, bounded just above the band: farther hits cannot change a decision inside it */
+        const float closest = hit->t;
+        *hit   = start;
+        hit->t = ( closest * PTO_BAND ) * PTO_BAND;
         cnt->redone++;
-        return bvh_intersect( d, o, dir, hit, cnt );
+        bvh_intersect( d, o, dir, hit, cnt );
+        if ( hit->prim < 0 )
+        {
+            *hit = start;
+            bvh_intersect( d, o, dir, hit, cnt );
+        }
+        return hit->t < start.t;
     }
     return hit->t < start.t;
 }

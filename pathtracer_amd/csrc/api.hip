@@ -90,7 +90,11 @@ int HostFailure( const char* where )
     do                                                                                                                   \
     {                                                                                                                    \
         hipError_t e_ = ( expr );                                                                                        \
-        if ( e_ != hipSuccess ) return Fail( PT_ERR_DEVICE, "%s failed: %s", #expr, hipGetErrorString( e_ ) );          \
+        if ( e_ != hipSuccess )                                                                                          \
+        {                                                                                                                \
+            (void)hipGetLastError(); /* reported here; a later call must not find it again */                           \
+            return Fail( PT_ERR_DEVICE, "%s failed: %s", #expr, hipGetErrorString( e_ ) );                              \
+        }                                                                                                                \
     } while ( 0 )
 
 // Device allocation that frees itself.
@@ -823,8 +827,16 @@ try
     if ( perPass * pixels > 0x7fffffffull ) return Fail( PT_ERR_INVALID_ARG, "pt_render: %llu samples per pass of %llu pixels exceeds 2^31 paths", (unsigned long long)perPass, (unsigned long long)pixels );
     if ( totalSamples > 0 )
     {
-        int rc = EnsurePathBuffers( s, perPass * pixels );
-        if ( rc != PT_OK ) return rc;
+        // A pass size the library chose itself is halved until its buffers fit: the memory that was free a moment ago
+        // may have gone to another scene on this GPU (several host threads, several processes).
+        for ( ;; )
+        {
+            const int rc = EnsurePathBuffers( s, perPass * pixels );
+            if ( rc == PT_OK ) break;
+            if ( p->samples_per_pass > 0 || perPass == 1 ) return rc;
+            (void)hipGetLastError();
+            perPass = ( perPass + 1 ) / 2;
+        }
     }
 
     RngParams rng{};

@@ -141,7 +141,10 @@ int pth_scene_info( PthScene* scene, PthSceneInfo* out )
     if ( !scene || !out ) return Fail( "pth_scene_info: null argument" );
     std::memset( out, 0, sizeof( *out ) );
     const auto& s = scene->scene;
-    out->num_spp  = static_cast< int32_t >( std::min< size_t >( s.numSamplesPerPixel.size(), 32 ) );
+    // the reference renders every entry of the list (src/main.cpp:32): dropping some silently would drop pictures
+    if ( s.numSamplesPerPixel.size() > 32 ) return Fail( "pth_scene_info: \"SamplesPerPixel\" has " + std::to_string( s.numSamplesPerPixel.size() ) + " entries, PthSceneInfo holds 32" );
+    if ( s.outputImageFilename.size() >= sizeof( out->output_filename ) ) return Fail( "pth_scene_info: the output file name is longer than 511 bytes" );
+    out->num_spp  = static_cast< int32_t >( s.numSamplesPerPixel.size() );
     for ( int i = 0; i < out->num_spp; ++i ) out->spp[i] = s.numSamplesPerPixel[i];
     out->samples_per_area_light = s.numSamplesPerAreaLight;
     out->split_method = s.splitMethod == pth::SplitMethod::SAH ? PTH_SPLIT_SAH

@@ -221,6 +221,24 @@ def test_invalid_scenes_are_rejected(scenes):
     assert e.value.code == abi.PT_ERR_INVALID_ARG
 
 
+def test_render_after_a_failed_growth_of_the_path_buffers(scenes):
+    """A pass that cannot be allocated (31 samples of 8192 x 8192 pixels in flight: 374 GB of path state) fails with
+    PT_ERR_DEVICE and leaves the scene usable: the next, smaller render allocates afresh and gives the checker's
+    counters.  With a pass size of the library's own choosing the same request succeeds in smaller passes."""
+    scene = scenes["cornell"].with_image(8192, 8192)
+    with api.DeviceScene(scene.to_desc()) as dev:
+        dev.render(1, seed=1, samples_per_pass=1)
+        first = dev.stats()
+        with pytest.raises(api.PtError) as e:
+            dev.render(31, seed=1, samples_per_pass=31)
+        assert e.value.code == abi.PT_ERR_DEVICE
+        dev.render(1, seed=1, samples_per_pass=1)
+        again = dev.stats()
+        assert again.samples == 8192 * 8192 and again.rays_closest == first.rays_closest and again.nodes_closest == first.nodes_closest
+        dev.render(3, seed=1)
+        assert dev.stats().samples == 3 * 8192 * 8192
+
+
 def test_film_tensor_and_single_rank_rccl_reduce(device_scenes):
     """The float4 film (sum r, g, b, sample count) is shared with torch without a copy and goes through one
     RCCL reduce; with one rank the reduce must leave it unchanged."""
