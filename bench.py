@@ -42,7 +42,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
-KERNEL_SOURCES = ("pathtracer_amd/csrc/kernels.hip", "pathtracer_amd/csrc/pt_device.h", "pathtracer_amd/csrc/pt_sincosf.h", "pathtracer_amd/csrc/pt_powf.h")
+KERNEL_SOURCES = ("pathtracer_amd/csrc/kernels.hip", "pathtracer_amd/csrc/pt_device.h", "pathtracer_amd/csrc/pt_sincosf.h", "pathtracer_amd/csrc/pt_powf.h", "pathtracer_amd/csrc/pt_acosf.h")
 
 
 def kernel_source_hash():

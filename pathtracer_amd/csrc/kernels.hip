@@ -25,6 +25,7 @@
 #include "pt_api.h"
 #include "pt_sincosf.h"
 #include "pt_powf.h"
+#include "pt_acosf.h"
 
 #include <float.h>
 
@@ -1260,7 +1261,8 @@ __global__ __launch_bounds__( kBlock ) void ShadeKernel( SceneView sv, RngParams
                 else
                 {
                     // Sphere::Intersect (src/shapes.cpp:61-73).  atan2 / sin / cos are the double functions in
-                    // the reference's build, acosf the float one.
+                    // the reference's build (accurate to a fraction of a double ulp on either side, so the rounded
+                    // floats agree but for about one call in a billion), acosf the float one.
                     const float4 q0 = sv.prims[4 * prim], q1 = sv.prims[4 * prim + 1];
                     const float4* s = sv.spheres + 6 * __float_as_uint( q1.y );
                     const float4 c0 = s[0], c1 = s[1], c2 = s[2], c3 = s[3];
@@ -1269,7 +1271,7 @@ __global__ __launch_bounds__( kBlock ) void ShadeKernel( SceneView sv, RngParams
                     f3 ld     = MatMul( c0, c1, c2, c3, d, 0.0f );
                     f3 lp     = lo + ld * t;
                     float theta = static_cast< float >( atan2( static_cast< double >( lp.z ), static_cast< double >( lp.x ) ) );
-                    float phi   = static_cast< float >( acos( static_cast< double >( -lp.y ) ) );
+                    float phi   = AcosLibm( -lp.y ); // the C library's acosf, which is not correctly rounded
                     tu        = -0.5f * ( theta / kPi + 1 );
                     tv        = phi / kPi;
                     double ds, dc;

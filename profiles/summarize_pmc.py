@@ -59,7 +59,7 @@ for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_stats.csv"), recur
 import hashlib
 repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 h = hashlib.sha256()
-for f in ("pathtracer_amd/csrc/kernels.hip", "pathtracer_amd/csrc/pt_device.h", "pathtracer_amd/csrc/pt_sincosf.h", "pathtracer_amd/csrc/pt_powf.h"):
+for f in ("pathtracer_amd/csrc/kernels.hip", "pathtracer_amd/csrc/pt_device.h", "pathtracer_amd/csrc/pt_sincosf.h", "pathtracer_amd/csrc/pt_powf.h", "pathtracer_amd/csrc/pt_acosf.h"):
     h.update(open(os.path.join(repo, f), "rb").read())
 out["_meta"] = {"kernel_sources": h.hexdigest()[:16], "traversal": traversal}
 

@@ -2,9 +2,8 @@
 the reference produced (tests/golden).
 
 Bars: hit primitive, t, u, v, occlusion bits and traversal counters are bit-exact.  Radiance in the
-deterministic modes (Philox or a replayed sample table): per pixel |gpu - cpu| <= 1e-4 * max(1, |cpu|), where the
-only arithmetic that is not bit-identical between the two is sin / cos / pow / atan2 / acos (device math library
-versus the host libm, both within an ulp); the tests also report how many pixels are exactly equal.
+deterministic modes (Philox or a replayed sample table): bit-exact too (see radiance_close; the stated tolerance of
+1e-4 * max(1, |cpu|) per pixel is kept as the outer bound).
 """
 import numpy as np
 import pytest
@@ -19,11 +18,17 @@ RADIANCE_TOL = 1e-4
 
 
 def radiance_close(gpu, cpu, what):
+    """Every operation of the path is restated to the CPU's bit (sin / cos / acos / pow of the C library included); the
+    one exception are the double-precision atan2 / sin / cos of a sphere hit's uv and tangent, whose device and host
+    versions can round a float differently about once in a billion calls.  So: all pixels equal, at most one may
+    differ, and that one within RADIANCE_TOL."""
     err = np.abs(gpu - cpu) / np.maximum(1.0, np.abs(cpu))
-    exact = (gpu == cpu).all(axis=-1).mean()
+    same = (gpu.view(np.uint32) == cpu.view(np.uint32)).all(axis=-1)
+    exact = same.mean()
     print(f"{what}: max err {err.max():.3e}, exactly equal pixels {100 * exact:.2f} %")
     assert np.isfinite(gpu).all(), f"{what}: non-finite radiance"
     assert err.max() <= RADIANCE_TOL, f"{what}: max relative error {err.max():.3e} at {np.unravel_index(err.argmax(), err.shape)}"
+    assert (~same).sum() <= 1, f"{what}: {(~same).sum()} pixels differ from the CPU's"
     return exact
 
 
@@ -115,8 +120,7 @@ def test_radiance_and_counters_match_oracle(name, device_scenes):
     dev.render(16, seed=123)
     lin, _, stats = dev.readback()
     want, ostats = orc.li_image(16, seed=123)
-    exact = radiance_close(lin, want / np.float32(16), f"{name} 16 spp vs oracle")
-    assert exact > 0.98
+    radiance_close(lin, want / np.float32(16), f"{name} 16 spp vs oracle")
     assert stats.rays_closest == ostats["rays_closest"]
     assert stats.nodes_closest == ostats["nodes_closest"]
     assert stats.tri_tests_closest == ostats["tri_tests_closest"]
