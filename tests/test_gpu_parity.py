@@ -143,6 +143,10 @@ def test_split_ranges_and_passes_are_bit_identical(device_scenes):
     dev.render(8, seed=3)
     again, _, _ = dev.readback()
     assert_bits_equal(whole, again, "repeat")
+    for kw in ({"samples_per_pass": 3}, {"samples_per_pass": 1, "ordered": True}, {"samples_per_pass": 5, "ordered": True}):
+        dev.render(8, seed=3, **kw)
+        assert_bits_equal(whole, dev.readback()[0], str(kw))
+        assert dev.stats().samples == 48 * 48 * 8
 
 
 def test_tonemap_matches_reference_vectors(device_scenes, golden):
