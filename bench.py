@@ -68,6 +68,7 @@ def parse():
     p.add_argument("--traversal", choices=("ordered", "reference"), default="ordered",
                    help="child visiting order of the BVH traversal: front to back (default; same hits and film, fewer node "
                         "visits) or the reference's first-child-first order (counters equal to the CPU's)")
+    p.add_argument("--scene-flags", type=int, default=0, help="PT_SCENE_* flags for pt_upload_scene (measurement switches)")
     p.add_argument("--cpu-baseline-spp", type=int, default=64, help="most samples per pixel the CPU baseline renders (0 = skip)")
     p.add_argument("--cpu-baseline-seconds", type=float, default=20.0, help="CPU time the baseline sample is sized for")
     p.add_argument("--save-image", default="", help="write the tonemapped frame of rank 0 to this file")
@@ -117,6 +118,7 @@ def main():
     hs = host.HostScene.atrium(seed=1, triangles=args.triangles, texture_size=args.texture_size)
     hs.set_image(args.width, args.height, args.width / args.height)
     desc = hs.desc(local_rank)
+    desc.flags |= args.scene_flags
     dev = api.DeviceScene(desc)
     setup_s = time.time() - t0
 
