@@ -174,7 +174,7 @@ public:
         for ( int g = 0; g < gpus; ++g )
             if ( !errors[g].empty() )
             {
-                std::cout << "GPU " << g << ": " << errors[g] << std::endl;
+                error = "GPU " + std::to_string( g ) + ": " + errors[g];
                 return false;
             }
         PtStats total{};
@@ -183,13 +183,13 @@ public:
             // the films are summed on the first GPU, the others' read in place over xGMI, in GPU order
             if ( pt_merge_films( m_scenes[0], m_scenes.data() + 1, static_cast< uint32_t >( gpus - 1 ) ) != PT_OK )
             {
-                std::cout << "merging the films: " << pt_last_error() << std::endl;
+                error = std::string( "merging the films: " ) + pt_last_error();
                 return false;
             }
             for ( int g = 1; g < gpus; ++g )
             {
                 PtStats one{};
-                if ( pt_readback( m_scenes[g], PT_TONEMAP_NONE, nullptr, nullptr, &one ) != PT_OK ) return false;
+                if ( pt_readback( m_scenes[g], PT_TONEMAP_NONE, nullptr, nullptr, &one ) != PT_OK ) return Failed( pt_last_error() );
                 Add( total, one );
             }
         }
@@ -197,11 +197,11 @@ public:
         PtStats first{};
         if ( m_hostTonemap )
         {
-            if ( pt_readback( m_scenes[0], PT_TONEMAP_UNCHARTED2, renderedImage.data(), nullptr, &first ) != PT_OK ) return false;
-            if ( pth_tonemap( renderedImage.data(), static_cast< uint64_t >( m_width ) * m_height, m_camera.exposure, m_camera.gamma, 0 ) != 0 ) return false;
+            if ( pt_readback( m_scenes[0], PT_TONEMAP_UNCHARTED2, renderedImage.data(), nullptr, &first ) != PT_OK ) return Failed( pt_last_error() );
+            if ( pth_tonemap( renderedImage.data(), static_cast< uint64_t >( m_width ) * m_height, m_camera.exposure, m_camera.gamma, 0 ) != 0 ) return Failed( pth_last_error() );
         }
         else if ( pt_readback( m_scenes[0], PT_TONEMAP_UNCHARTED2, nullptr, renderedImage.data(), &first ) != PT_OK )
-            return false;
+            return Failed( pt_last_error() );
         Add( total, first );
         if ( stats ) *stats = total;
         const double seconds = std::chrono::duration< double >( std::chrono::steady_clock::now() - timeStart ).count();
@@ -212,8 +212,15 @@ public:
     bool SaveImage( const std::string& filename ) const { return pth_write_image( filename.c_str(), renderedImage.data(), m_width, m_height ) == 0; }
 
     std::vector< float > renderedImage;
+    std::string error; // what made Render return false (the library keeps its messages per thread, and the GPUs render from threads of their own)
 
 private:
+    bool Failed( const char* message )
+    {
+        error = message;
+        return false;
+    }
+
     // counters add up over the GPUs; the GPUs run side by side, so the time is the longest of theirs
     static void Add( PtStats& sum, const PtStats& one )
     {
@@ -319,7 +326,7 @@ int main( int argc, char** argv )
         const uint64_t seed = opt.haveSeed ? opt.seed : ( static_cast< uint64_t >( entropy() ) << 32 | entropy() );
         if ( !pathTracer.Render( sppList[it], seed, &stats ) )
         {
-            std::cout << "Render failed: " << pt_last_error() << std::endl;
+            std::cout << "Render failed: " << pathTracer.error << std::endl;
             break;
         }
         if ( opt.stats )
