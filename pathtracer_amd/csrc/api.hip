@@ -15,7 +15,9 @@
 #include <mutex>
 #include <new>
 #include <queue>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace ptd;
@@ -140,6 +142,36 @@ float Dot( f3h a, f3h b ) { return ( a.x * b.x + a.y * b.y ) + a.z * b.z; }
 f3h Load3( const float* p ) { return { p[0], p[1], p[2] }; }
 
 constexpr float kPiHost = 3.14159265358979323846f;
+
+// The per-node and per-primitive loops of an upload, spread over host threads once they are long enough to pay for
+// the threads (a 20 M triangle scene: 3.7 s of record building on one thread).  body( begin, end ) must not throw and
+// must touch only what belongs to its range; the ranges are handed out in chunks, smallest index first.
+template < typename Body >
+void ParallelFor( uint64_t n, const Body& body )
+{
+    constexpr uint64_t kChunk = 1u << 16;
+    unsigned threads = std::thread::hardware_concurrency();
+    if ( threads > 16 ) threads = 16; // a share of a large machine, not all of it
+    if ( threads < 2 || n < 4 * kChunk )
+    {
+        if ( n ) body( uint64_t( 0 ), n );
+        return;
+    }
+    std::atomic< uint64_t > next{ 0 };
+    auto work = [&] {
+        for ( ;; )
+        {
+            const uint64_t begin = next.fetch_add( kChunk );
+            if ( begin >= n ) return;
+            body( begin, begin + kChunk < n ? begin + kChunk : n );
+        }
+    };
+    std::vector< std::thread > pool;
+    pool.reserve( threads - 1 );
+    for ( unsigned t = 1; t < threads; ++t ) pool.emplace_back( work );
+    work();
+    for ( std::thread& t : pool ) t.join();
+}
 
 } // namespace
 
@@ -342,26 +374,28 @@ int Upload( PtScene* s, const PtSceneDesc* d, const std::vector< uint32_t >& esc
         s->topNodes = static_cast< uint32_t >( bfs.size() );
     }
 
-    std::vector< float > nodes( 8ull * N );
-    for ( uint32_t i = 0; i < N; ++i )
-    {
-        const PtBvhNode& n = d->nodes[i];
-        float* o = &nodes[8ull * place[i]];
-        o[0] = n.aabb_min[0]; o[1] = n.aabb_min[1]; o[2] = n.aabb_max[0]; o[3] = n.aabb_max[1];
-        o[4] = n.aabb_min[2]; o[5] = n.aabb_max[2];
-        // link word: where to go after this node's subtree, top bit set for a leaf; second word: the leaf's
-        // primitives, or the first child of an inner node
-        uint32_t link = place[escape[i]], word = place[i + 1 <= N ? i + 1 : N];
-        if ( n.num_shapes > 0 )
+    std::unique_ptr< float[] > nodes( new float[8ull * N] ); // every word is written below
+    ParallelFor( N, [&]( uint64_t begin, uint64_t end ) {
+        for ( uint64_t i = begin; i < end; ++i )
         {
-            link |= kLeafFlag;
-            word = static_cast< uint32_t >( n.offset ) | ( static_cast< uint32_t >( n.num_shapes - 1 ) << 28 );
+            const PtBvhNode& n = d->nodes[i];
+            float* o = &nodes[8ull * place[i]];
+            o[0] = n.aabb_min[0]; o[1] = n.aabb_min[1]; o[2] = n.aabb_max[0]; o[3] = n.aabb_max[1];
+            o[4] = n.aabb_min[2]; o[5] = n.aabb_max[2];
+            // link word: where to go after this node's subtree, top bit set for a leaf; second word: the leaf's
+            // primitives, or the first child of an inner node
+            uint32_t link = place[escape[i]], word = place[i + 1];
+            if ( n.num_shapes > 0 )
+            {
+                link |= kLeafFlag;
+                word = static_cast< uint32_t >( n.offset ) | ( static_cast< uint32_t >( n.num_shapes - 1 ) << 28 );
+            }
+            std::memcpy( &o[6], &link, 4 );
+            std::memcpy( &o[7], &word, 4 );
         }
-        std::memcpy( &o[6], &link, 4 );
-        std::memcpy( &o[7], &word, 4 );
-    }
-    HIP_TRY( s->nodes.Upload( nodes.data(), nodes.size() * 4 ) );
-    nodes = std::vector< float >();
+    } );
+    HIP_TRY( s->nodes.Upload( nodes.get(), 32ull * N ) );
+    nodes.reset();
 
     // Second layout, for front-to-back traversal (kernels.hip, TraceClosestOrdered): 64-byte records, the root at 0,
     // record 1 unused, then sibling pairs at even indices - the top of the tree in the same order as above, below it
@@ -403,10 +437,12 @@ int Upload( PtScene* s, const PtSceneDesc* d, const std::vector< uint32_t >& esc
             }
         }
         numOrdered = next; // N + 1
-        std::vector< uint32_t > rec( 16ull * numOrdered, 0u );
+        // every word of a record is written below - the box and the two words by its own node, the links by its parent -
+        // except the unused record 1
+        std::unique_ptr< uint32_t[] > rec( new uint32_t[16ull * numOrdered] );
+        std::memset( &rec[16], 0, 64 );
         for ( int o = 0; o < 8; ++o ) rec[8 + o] = numOrdered; // after the root's subtree: the end
-        for ( uint32_t i = 0; i < N; ++i )                     // parents come before their children in the reference's order
-        {
+        auto fill = [&]( uint32_t i ) {                        // a node's parent must have been filled before it
             const PtBvhNode& n = d->nodes[i];
             uint32_t* r = &rec[16ull * at[i]];
             std::memcpy( &r[0], &n.aabb_min[0], 4 ); std::memcpy( &r[1], &n.aabb_min[1], 4 );
@@ -416,7 +452,7 @@ int Upload( PtScene* s, const PtSceneDesc* d, const std::vector< uint32_t >& esc
             {
                 r[6] = static_cast< uint32_t >( n.offset ) | ( static_cast< uint32_t >( n.num_shapes - 1 ) << 28 );
                 r[7] = kLeafFlag;
-                continue;
+                return;
             }
             const uint32_t a = i + 1, b = static_cast< uint32_t >( n.offset );
             const uint32_t axis = n.axis < 3 ? n.axis : 0; // any choice of the near child gives the same hits
@@ -430,14 +466,57 @@ int Upload( PtScene* s, const PtSceneDesc* d, const std::vector< uint32_t >& esc
                 ( secondIsNear ? rb : ra )[8 + o] = secondIsNear ? at[a] : at[b]; // after the near child's subtree: its sibling
                 ( secondIsNear ? ra : rb )[8 + o] = r[8 + o];                      // after the far child's: what follows the parent
             }
+        };
+        // The nodes of a subtree are a contiguous range of the reference's pre-order, parents before children, and
+        // depend on nothing outside it but the subtree root's parent.  The top of the tree is filled first, largest
+        // subtree split first, then the subtrees below it side by side.
+        std::vector< uint32_t > upper, roots;
+        {
+            std::priority_queue< std::pair< uint32_t, uint32_t > > open; // (nodes in the subtree, its root)
+            open.push( { N, 0u } );
+            while ( !open.empty() && open.size() + roots.size() < 1024 )
+            {
+                const uint32_t size = open.top().first, x = open.top().second;
+                open.pop();
+                if ( d->nodes[x].num_shapes > 0 || size < 8192 )
+                {
+                    roots.push_back( x );
+                    continue;
+                }
+                upper.push_back( x );
+                const uint32_t a = x + 1, b = static_cast< uint32_t >( d->nodes[x].offset );
+                open.push( { escape[a] - a, a } );
+                open.push( { escape[b] - b, b } );
+            }
+            for ( ; !open.empty(); open.pop() ) roots.push_back( open.top().second );
+            std::sort( upper.begin(), upper.end() ); // a parent's index is below its children's
         }
-        HIP_TRY( s->orderedNodes.Upload( rec.data(), rec.size() * 4 ) );
+        for ( uint32_t x : upper ) fill( x );
+        {
+            std::atomic< size_t > nextRoot{ 0 };
+            auto work = [&] {
+                for ( size_t k = nextRoot.fetch_add( 1 ); k < roots.size(); k = nextRoot.fetch_add( 1 ) )
+                    for ( uint32_t i = roots[k], end = escape[roots[k]]; i < end; ++i ) fill( i );
+            };
+            unsigned threads = std::thread::hardware_concurrency();
+            if ( threads > 16 ) threads = 16;
+            if ( N < ( 1u << 18 ) || threads < 2 ) threads = 1;
+            std::vector< std::thread > pool;
+            for ( unsigned t = 1; t < threads; ++t ) pool.emplace_back( work );
+            work();
+            for ( std::thread& t : pool ) t.join();
+        }
+        HIP_TRY( s->orderedNodes.Upload( rec.get(), 64ull * numOrdered ) );
     }
 
-    std::vector< float > prims( 16ull * P, 0.0f ), shade( 32ull * P, 0.0f ); // 112 bytes of attributes in a 128-byte slot: one L2 line per record
-    for ( uint64_t i = 0; i < P; ++i )
+    // 112 bytes of attributes in a 128-byte slot: one L2 line per record
+    std::unique_ptr< float[] > prims( new float[16ull * P] ), shade( new float[32ull * P] );
+    ParallelFor( P, [&]( uint64_t begin, uint64_t end ) {
+    for ( uint64_t i = begin; i < end; ++i )
     {
         float* q = &prims[16 * i];
+        std::memset( q, 0, 64 );
+        std::memset( &shade[32 * i], 0, 128 );
         if ( d->prims[i].type == PT_PRIM_TRIANGLE )
         {
             const PtTriangle& t = d->triangles[d->prims[i].index];
@@ -470,8 +549,11 @@ int Upload( PtScene* s, const PtSceneDesc* d, const std::vector< uint32_t >& esc
             std::memcpy( &q[5], &index, 4 );
         }
     }
-    HIP_TRY( s->prims.Upload( prims.data(), prims.size() * 4 ) );
-    HIP_TRY( s->triShade.Upload( shade.data(), shade.size() * 4 ) );
+    } );
+    HIP_TRY( s->prims.Upload( prims.get(), 64ull * P ) );
+    HIP_TRY( s->triShade.Upload( shade.get(), 128ull * P ) );
+    prims.reset();
+    shade.reset();
 
     std::vector< float > spheres( 24ull * d->num_spheres, 0.0f );
     for ( uint64_t i = 0; i < d->num_spheres; ++i )

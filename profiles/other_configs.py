@@ -19,7 +19,9 @@ from pathtracer_amd.scene import SceneData  # noqa: E402
 
 def measure(name, desc, spp, repeats=3, ordered=True, flags=0):
     desc.flags |= flags
+    t_upload = time.time()
     with api.DeviceScene(desc) as dev:
+        t_upload = time.time() - t_upload
         dev.render(min(spp, 2), seed=1, ordered=ordered)  # warm-up: allocations, code upload
         dev.readback()
         best = None
@@ -36,7 +38,7 @@ def measure(name, desc, spp, repeats=3, ordered=True, flags=0):
             "mrays_per_s": round(rays / best.render_ms * 1e-3, 1),
             "msamples_per_s": round(best.samples / best.render_ms * 1e-3, 1),
             "extend_ms": round(best.kernel_ms[1], 3), "shade_ms": round(best.kernel_ms[2], 3), "connect_ms": round(best.kernel_ms[3], 3),
-            "rays_redone": int(best.rays_redone),
+            "rays_redone": int(best.rays_redone), "upload_s": round(t_upload, 3),
             "nodes_per_ray": round((best.nodes_closest + best.nodes_shadow) / rays, 2),
             "prim_tests_per_ray": round((best.tri_tests_closest + best.tri_tests_shadow + best.sphere_tests_closest
                                          + best.sphere_tests_shadow) / rays, 3),
