@@ -150,6 +150,9 @@ enum
     PT_SCENE_NO_DIRECT_SUM    = 1u << 0, /* always run the separate direct-light summation pass (PT_K_RESOLVE), also for
                                             a scene with one light and one sample per hit                             */
     PT_SCENE_TOP_BREADTH_FIRST = 1u << 1, /* top of the tree in plain breadth-first order instead of largest box first */
+    PT_SCENE_NO_PARALLEL_SHADOWS = 1u << 3, /* do not build the light-space node layout that PT_RENDER_ORDERED uses
+                                             for the shadow rays of a scene lit by one directional light (same
+                                             picture either way; for measurements)                                     */
     PT_SCENE_NO_ORDERED_LAYOUT = 1u << 2  /* do not build the second node layout that PT_RENDER_ORDERED and
                                             PT_TRAVERSAL_ORDERED need (64 bytes of device memory per node); those
                                             then fail with PT_ERR_STATE                                               */
@@ -209,7 +212,9 @@ enum
 {
     PT_RENDER_ACCUMULATE = 1u << 0, /* keep the film of earlier pt_render calls and add to it          */
     PT_RENDER_PROFILE    = 1u << 1, /* bracket every kernel class with events (PtStats::kernel_ms)     */
-    PT_RENDER_ORDERED    = 1u << 2  /* front-to-back traversal, see PT_TRAVERSAL_ORDERED                   */
+    PT_RENDER_ORDERED    = 1u << 2  /* front-to-back traversal, see PT_TRAVERSAL_ORDERED; in a scene lit by one
+                                       directional light the shadow rays, all parallel, are traced in the light's
+                                       space (same occlusion answers, other node counts)                          */
 };
 
 /* Order in which a ray visits the children of an inner BVH node.

@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <exception>
+#include <limits>
 #include <memory>
 #include <mutex>
 #include <new>
@@ -185,7 +186,7 @@ struct PtScene
     bool directSum = false;                         // one light with one sample: ConnectKernel adds the direct light, no ResolveKernel
 
     // scene
-    DeviceBuffer nodes, orderedNodes, prims, triShade, spheres, materials, textures, texels, lights, skybox;
+    DeviceBuffer nodes, orderedNodes, shadowNodes, shadowTopWords, prims, triShade, spheres, materials, textures, texels, lights, skybox;
     SceneView view{};
     PtCamera camera{};
     int width = 0, height = 0, maxDepth = 0;
@@ -509,6 +510,160 @@ int Upload( PtScene* s, const PtSceneDesc* d, const std::vector< uint32_t >& esc
         HIP_TRY( s->orderedNodes.Upload( rec.get(), 64ull * numOrdered ) );
     }
 
+    // Third layout, for the shadow rays of a scene whose one light is directional (kernels.hip, ConnectParallelKernel):
+    // every such ray has the light's direction, so in a frame with one axis along it a node's box is a rectangle and
+    // one depth.  16-byte records {x0 | width << 16, y0 | height << 16, wmax, word}: the rectangle on a 16-bit grid
+    // over the root's, rounded outwards with cells to spare for the rounding of the ray's own projection; wmax
+    // the largest depth (towards the light) of the box, rounded up.  The records are outer bounds only: a hit
+    // found through them counts once the reference's own test of its leaf's box has passed (the box travels in the
+    // primitive record).  Order: the first numShadowTop records are the top of the tree (as in the other layouts) and
+    // are read from LDS with a second word each; the rest follows in the reference's pre-order, where an inner
+    // node's first child is the next record and a leaf is followed by the next record too - so one word serves:
+    // word = link for an inner node (where to go when its box is missed), leaf flag | leaf word for a leaf.  A
+    // leaf of the lower part whose successor lies in the top part gets a record of its own behind it that no ray enters
+    // (wmax = -inf) and that links there.  Top records: inner {link, first child}, leaf {flag | leaf word, link}.
+    uint32_t numShadow = 0, shadowTop = 0;
+    if ( !( d->flags & PT_SCENE_NO_PARALLEL_SHADOWS ) && d->num_lights == 1 && d->lights[0].type == PT_LIGHT_DIRECTIONAL )
+    {
+        const double w[3] = { -static_cast< double >( d->lights[0].direction[0] ), -static_cast< double >( d->lights[0].direction[1] ),
+                              -static_cast< double >( d->lights[0].direction[2] ) }; // wi of src/lights.cpp:30
+        const double wLen = std::sqrt( w[0] * w[0] + w[1] * w[1] + w[2] * w[2] );
+        float fu[3] = { 0, 0, 0 }, fv[3] = { 0, 0, 0 }, fw[3] = { static_cast< float >( w[0] ), static_cast< float >( w[1] ), static_cast< float >( w[2] ) };
+        const int zeros = ( w[0] == 0 ) + ( w[1] == 0 ) + ( w[2] == 0 );
+        bool build = std::isfinite( wLen ) && wLen > 0;
+        // a record's word keeps bit 31 for the leaf flag, which leaves three bits for a leaf's shape count
+        for ( uint32_t i = 0; i < N && build; ++i ) build = d->nodes[i].num_shapes <= 8;
+        if ( build && zeros == 2 )
+        {
+            // along an axis: the other two axes as they are, and the projections are exact
+            const int k = w[0] != 0 ? 0 : w[1] != 0 ? 1 : 2;
+            fu[( k + 1 ) % 3] = 1.0f;
+            fv[( k + 2 ) % 3] = 1.0f;
+        }
+        else if ( build )
+        {
+            int k = 0; // the axis the direction leans on least
+            for ( int a = 1; a < 3; ++a )
+                if ( std::fabs( w[a] ) < std::fabs( w[k] ) ) k = a;
+            double e[3] = { 0, 0, 0 };
+            e[k] = 1;
+            double u[3] = { w[1] * e[2] - w[2] * e[1], w[2] * e[0] - w[0] * e[2], w[0] * e[1] - w[1] * e[0] };
+            const double uLen = std::sqrt( u[0] * u[0] + u[1] * u[1] + u[2] * u[2] );
+            for ( int a = 0; a < 3; ++a ) u[a] /= uLen;
+            double v[3] = { w[1] * u[2] - w[2] * u[1], w[2] * u[0] - w[0] * u[2], w[0] * u[1] - w[1] * u[0] };
+            for ( int a = 0; a < 3; ++a )
+            {
+                fu[a] = static_cast< float >( u[a] );
+                fv[a] = static_cast< float >( v[a] / wLen );
+            }
+        }
+        // what the device's single-precision projection of a point of the scene can be off by
+        double maxAbs = 0;
+        for ( int a = 0; a < 3; ++a ) maxAbs = std::max( { maxAbs, std::fabs( static_cast< double >( d->nodes[0].aabb_min[a] ) ), std::fabs( static_cast< double >( d->nodes[0].aabb_max[a] ) ) } );
+        const double projectionError = zeros == 2 ? 0.0 : std::ldexp( maxAbs, -20 );
+        auto project = [&]( const PtBvhNode& n, const float* axis, double* lo, double* hi ) {
+            *lo = std::numeric_limits< double >::infinity();
+            *hi = -*lo;
+            for ( int c = 0; c < 8; ++c )
+            {
+                const double x = c & 1 ? n.aabb_max[0] : n.aabb_min[0], y = c & 2 ? n.aabb_max[1] : n.aabb_min[1], z = c & 4 ? n.aabb_max[2] : n.aabb_min[2];
+                const double p = x * axis[0] + y * axis[1] + z * axis[2];
+                *lo = std::min( *lo, p );
+                *hi = std::max( *hi, p );
+            }
+        };
+        double origin[2] = { 0, 0 }, cell[2] = { 1, 1 };
+        float invCell[2] = { 1, 1 }, originF[2] = { 0, 0 };
+        int slack[2] = { 2, 2 };
+        for ( int a = 0; a < 2 && build; ++a )
+        {
+            double lo, hi;
+            project( d->nodes[0], a == 0 ? fu : fv, &lo, &hi );
+            build = std::isfinite( lo ) && std::isfinite( hi );
+            if ( !build ) break;
+            cell[a]    = std::max( { ( hi - lo ) / 64000.0, std::ldexp( maxAbs, -18 ), 1e-30 } );
+            invCell[a] = static_cast< float >( 1.0 / cell[a] );
+            cell[a]    = 1.0 / static_cast< double >( invCell[a] ); // the cell the device's multiplication implies
+            // the device computes floor( ( p - origin ) * invCell ) in single precision: its p is off by projectionError,
+            // the subtraction and the product by a few ulps of a number below 2^16
+            const int need = 2 + static_cast< int >( std::ceil( projectionError / cell[a] ) );
+            slack[a]   = need;
+            originF[a] = static_cast< float >( lo - ( need + 2 ) * cell[a] );
+            origin[a]  = originF[a];
+            build      = std::isfinite( originF[a] ) && std::isfinite( invCell[a] ) && ( hi - origin[a] ) / cell[a] + need + 2 < 65534.0;
+        }
+        if ( build )
+        {
+            const uint32_t unset = 0xFFFFFFFFu;
+            shadowTop = static_cast< uint32_t >( std::min< size_t >( bfs.size(), kShadowTopNodes ) );
+            std::vector< uint32_t > sp( N + 1, unset ); // reference index -> record
+            for ( uint32_t k = 0; k < shadowTop; ++k ) sp[bfs[k]] = k;
+            std::vector< std::pair< uint32_t, uint32_t > > jumps; // (record, reference index of its target)
+            uint32_t next = shadowTop;
+            for ( uint32_t i = 0; i < N; ++i )
+            {
+                if ( sp[i] != unset ) continue;
+                sp[i] = next++;
+                if ( d->nodes[i].num_shapes > 0 && escape[i] < N && sp[escape[i]] != unset && sp[escape[i]] < shadowTop ) jumps.push_back( { next++, escape[i] } );
+            }
+            numShadow = next;
+            sp[N]     = numShadow; // the end of the traversal
+            std::unique_ptr< float[] > rec( new float[4ull * numShadow] );
+            std::vector< uint32_t > topWords( shadowTop, 0u );
+            ParallelFor( N, [&]( uint64_t begin, uint64_t end ) {
+                for ( uint64_t i = begin; i < end; ++i )
+                {
+                    const PtBvhNode& n = d->nodes[i];
+                    uint32_t q[2];
+                    for ( int a = 0; a < 2; ++a )
+                    {
+                        double lo, hi;
+                        project( n, a == 0 ? fu : fv, &lo, &hi );
+                        const double qlo = std::min( 65534.0, std::max( 1.0, std::floor( ( lo - origin[a] ) / cell[a] ) - slack[a] ) );
+                        const double qhi = std::min( 65534.0, std::max( qlo, std::ceil( ( hi - origin[a] ) / cell[a] ) + slack[a] ) );
+                        q[a] = static_cast< uint32_t >( qlo ) | static_cast< uint32_t >( qhi - qlo ) << 16;
+                    }
+                    double wlo, whi;
+                    project( n, fw, &wlo, &whi );
+                    whi += projectionError;
+                    float wmax = static_cast< float >( whi );
+                    if ( static_cast< double >( wmax ) < whi ) wmax = std::nextafter( wmax, std::numeric_limits< float >::infinity() );
+                    const bool leaf     = n.num_shapes > 0;
+                    const uint32_t link = sp[escape[i]];
+                    const uint32_t word = leaf ? kLeafFlag | static_cast< uint32_t >( n.offset ) | ( static_cast< uint32_t >( n.num_shapes - 1 ) << 28 ) : link;
+                    float* r = &rec[4ull * sp[i]];
+                    std::memcpy( &r[0], &q[0], 4 );
+                    std::memcpy( &r[1], &q[1], 4 );
+                    r[2] = wmax;
+                    std::memcpy( &r[3], &word, 4 );
+                    if ( sp[i] < shadowTop ) topWords[sp[i]] = leaf ? link : sp[i + 1];
+                }
+            } );
+            for ( const auto& j : jumps )
+            {
+                float* r = &rec[4ull * j.first];
+                const uint32_t one = 1u, link = sp[j.second];
+                std::memcpy( &r[0], &one, 4 );
+                std::memcpy( &r[1], &one, 4 );
+                r[2] = -std::numeric_limits< float >::infinity();
+                std::memcpy( &r[3], &link, 4 );
+            }
+            HIP_TRY( s->shadowNodes.Upload( rec.get(), 16ull * numShadow ) );
+            HIP_TRY( s->shadowTopWords.Upload( topWords.data(), 4ull * shadowTop ) );
+            for ( int a = 0; a < 3; ++a )
+            {
+                s->view.lightU[a] = fu[a];
+                s->view.lightV[a] = fv[a];
+                s->view.lightW[a] = fw[a];
+            }
+            for ( int a = 0; a < 2; ++a )
+            {
+                s->view.shadowOrigin[a]  = originF[a];
+                s->view.shadowInvCell[a] = invCell[a];
+            }
+        }
+    }
+
     // 112 bytes of attributes in a 128-byte slot: one L2 line per record
     std::unique_ptr< float[] > prims( new float[16ull * P] ), shade( new float[32ull * P] );
     ParallelFor( P, [&]( uint64_t begin, uint64_t end ) {
@@ -549,6 +704,19 @@ int Upload( PtScene* s, const PtSceneDesc* d, const std::vector< uint32_t >& esc
             std::memcpy( &q[5], &index, 4 );
         }
     }
+    } );
+    // every primitive record carries the box of its leaf in the words the tests above leave free (7, 11, 12 - 15)
+    ParallelFor( N, [&]( uint64_t begin, uint64_t end ) {
+        for ( uint64_t i = begin; i < end; ++i )
+        {
+            const PtBvhNode& n = d->nodes[i];
+            for ( uint32_t k = 0; k < n.num_shapes; ++k )
+            {
+                float* q = &prims[16ull * ( static_cast< uint64_t >( n.offset ) + k )];
+                q[7] = n.aabb_min[0]; q[11] = n.aabb_min[1]; q[12] = n.aabb_min[2];
+                q[13] = n.aabb_max[0]; q[14] = n.aabb_max[1]; q[15] = n.aabb_max[2];
+            }
+        }
     } );
     HIP_TRY( s->prims.Upload( prims.get(), 64ull * P ) );
     HIP_TRY( s->triShade.Upload( shade.get(), 128ull * P ) );
@@ -637,6 +805,10 @@ int Upload( PtScene* s, const PtSceneDesc* d, const std::vector< uint32_t >& esc
     SceneView& v    = s->view;
     v.nodes         = s->nodes.As< float4 >();
     v.orderedNodes  = s->orderedNodes.As< float4 >();
+    v.shadowNodes   = s->shadowNodes.As< float4 >();
+    v.shadowTopWords = s->shadowTopWords.As< uint32_t >();
+    v.numShadowNodes = numShadow;
+    v.numShadowTop  = shadowTop;
     v.numOrderedNodes = numOrdered;
     v.numTopOrdered = topOrdered;
     v.prims         = s->prims.As< float4 >();

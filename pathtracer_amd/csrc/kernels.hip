@@ -1169,6 +1169,168 @@ __global__ __launch_bounds__( kConnectBlock ) PT_CONNECT_OCCUPANCY void ConnectK
     FlushWaveCounter( stats, ST_STEPS_SHADOW, waveSteps );
 }
 
+// Shadow rays of a scene lit by one directional light (src/lights.cpp:25-38): they all have the light's direction,
+// so BVH::Occluded (src/bvh.cpp:270-310) becomes a search in two dimensions.  In the light's frame - lightU and lightV
+// across the direction, lightW along it, towards the light - a ray is a point (u, v) and a depth w, a node's box a
+// rectangle and the depth range it covers, and the box can only be entered if the point lies in the rectangle and the
+// box reaches beyond the ray's depth.  The records of the third node layout (api.hip) hold exactly that, as an outer
+// bound: 16 bytes per node visit instead of 32, four integer compares and a float compare instead of the slab
+// arithmetic, and no per-ray reciprocal.  Being outer bounds, they may lead to a primitive that the reference's
+// descent never reaches; the answer stays the reference's because a hit only counts if the reference's test of the
+// primitive's leaf box passes (with it, the boxes being nested, those of all its ancestors): any-hit asks whether SOME
+// primitive that the reference can reach is hit, and the order of the search does not matter.
+// State per lane: the point as two grid cells, the depth, and the origin for the primitive tests.
+// (Two rays per lane, to have twice the loads in flight: 31.2 ms against 24.7 per 32 samples per pixel of the
+// benchmark's frame - the kernel does not wait for single loads but for the memory pipeline as a whole.)
+template < bool kDirectSum >
+__global__ __launch_bounds__( kConnectBlock ) PT_CONNECT_OCCUPANCY void ConnectParallelKernel( SceneView sv, PathBuffers pb, int bounce, uint64_t* stats )
+{
+    UnitStream stream{ pb.cursors + 2 * bounce + 1, UnitCount( pb, bounce, kCountShadowRays, 0 ), pb.units, kUnitPaths * pb.shadowSlots, 0u };
+    const uint32_t end      = sv.numShadowNodes;
+    const uint32_t entries  = pb.units * kUnitPaths;
+    const uint32_t topCount = sv.numShadowTop; // at most kShadowTopNodes
+    const BufferDesc nodes  = MakeBuffer( sv.shadowNodes, sv.numShadowNodes * 16u );
+    const SceneBuffers sb{ nodes, MakeBuffer( sv.prims, sv.numPrims * 64u ) };
+    __shared__ float4 topLds[kShadowTopNodes];
+    __shared__ uint32_t topWords[kShadowTopNodes];
+    for ( uint32_t i = threadIdx.x; i < topCount; i += kConnectBlock )
+    {
+        topLds[i]   = Load16( nodes, 16u * i );
+        topWords[i] = sv.shadowTopWords[i];
+    }
+    __syncthreads();
+    // the one direction, as ShadeKernel wrote it into every record (wi = -direction), and what BVH::Occluded derives from it
+    const f3 d    = -F3( sv.lights[0].a );
+    const f3 inv  = F3( 1.0f / d.x, 1.0f / d.y, 1.0f / d.z ); // bvh.cpp:275-276
+    const bool nx = inv.x < 0, ny = inv.y < 0, nz = inv.z < 0;
+    constexpr float tMax = FLT_MAX;                            // src/lights.cpp:35
+    const f3 axisU = F3( sv.lightU ), axisV = F3( sv.lightV ), axisW = F3( sv.lightW );
+    uint32_t rec = kNoRay, node = end, leaf = kInnerNode;
+    f3 o = F3( 0.0f, 0.0f, 0.0f );
+    uint32_t cell = 0; // the ray's point: its grid cell along u in the low half, along v in the high half
+    float pw = 0.0f;   // the ray's depth
+    bool occluded = false;
+    uint32_t waveRays = 0, waveNodes = 0, waveTris = 0, waveSpheres = 0, waveSteps = 0; // whole-wave totals, wave-uniform
+
+    for ( ;; )
+    {
+        const bool atLeaf = leaf != kInnerNode;
+        const bool idle   = node == end && !atLeaf;
+        const unsigned long long mLeaf = Ballot( atLeaf ), mEnd = Ballot( node == end );
+        const unsigned long long mTrav = ~mEnd & ~mLeaf;
+        const unsigned long long mRay  = mEnd & ~mLeaf & ( stream.ended ? Ballot( rec != kNoRay ) : ~0ull );
+        if ( ( mLeaf | mTrav | mRay ) == 0 ) break;
+
+        if ( mRay && ( __popcll( mRay ) >= kConnectRefillLanes || ( mTrav | mLeaf ) == 0 ) )
+        {
+            if constexpr ( kDirectSum )
+            {
+                if ( idle && rec != kNoRay && !occluded )
+                {
+                    const float4 e = pb.shEst[rec];
+                    const uint32_t p = __float_as_uint( e.w );
+                    pb.rad[p] = F4( F3( pb.rad[p] ) + F3( e ), 0.0f );
+                }
+            }
+            else if ( idle && rec != kNoRay && occluded )
+                reinterpret_cast< float* >( pb.shDir )[4ull * rec + 3] = -2.0f;
+            if ( idle ) rec = kNoRay;
+            while ( !stream.ended )
+            {
+                const unsigned long long mIdle = Ballot( idle && rec == kNoRay );
+                if ( mIdle == 0 ) break;
+                if ( stream.taken == stream.count )
+                {
+                    NextUnit( stream );
+                    continue;
+                }
+                const uint32_t left = stream.count - stream.taken, asking = static_cast< uint32_t >( __popcll( mIdle ) );
+                const uint32_t rank = LanesBelow( mIdle );
+                if ( idle && rec == kNoRay && rank < left )
+                {
+                    rec = pb.shadowRays[stream.base + stream.taken + rank];
+                    const uint32_t entry = pb.shadowSlots == 1 ? rec : rec % entries; // record index = slot * entries + entry
+                    o = F3( pb.shadowO[entry] );
+                    // the cell the ray's point falls into (the conversion saturates; cells 0 and 65535 lie outside every rectangle)
+                    const float gu = ( Dot( o, axisU ) - sv.shadowOrigin[0] ) * sv.shadowInvCell[0];
+                    const float gv = ( Dot( o, axisV ) - sv.shadowOrigin[1] ) * sv.shadowInvCell[1];
+                    cell = static_cast< uint32_t >( __builtin_fminf( __builtin_fmaxf( gu, 0.0f ), 65535.0f ) ) |
+                           static_cast< uint32_t >( __builtin_fminf( __builtin_fmaxf( gv, 0.0f ), 65535.0f ) ) << 16;
+                    pw = Dot( o, axisW );
+                    occluded = false;
+                    node     = 0;
+                }
+                const uint32_t given = asking < left ? asking : left;
+                stream.taken += given;
+                waveRays += given;
+            }
+            continue;
+        }
+
+        if ( mLeaf && ( __popcll( mLeaf ) >= kLeafLanes || mTrav == 0 ) )
+        {
+            const uint32_t first = leaf & kLeafFirstMask;
+            uint32_t shapes = atLeaf ? ( leaf >> 28 ) + 1 : 0;
+            for ( uint32_t k = 0; Ballot( k < shapes ) != 0; ++k ) // bvh.cpp:287-293: stop at the first hit
+            {
+                bool isTri = false, isSphere = false;
+                if ( k < shapes )
+                {
+                    const uint32_t prim = first + k;
+                    if ( AnyPrimTest( sb, prim, o, d, tMax, &isSphere ) )
+                    {
+                        // the reference reaches this primitive only through its leaf's box (bvh.cpp:282)
+                        const float4 q1 = Load16( sb.prims, 64u * prim + 16u ), q2 = Load16( sb.prims, 64u * prim + 32u ), q3 = Load16( sb.prims, 64u * prim + 48u );
+                        if ( RayBox( o, inv, nx, ny, nz, make_float4( q1.w, q2.w, q3.y, q3.z ), make_float4( q3.x, q3.w, 0.0f, 0.0f ), tMax ) )
+                        {
+                            occluded = true;
+                            shapes   = 0;
+                            node     = end;
+                        }
+                    }
+                    isTri = !isSphere;
+                }
+                waveTris += LanesSet( isTri );
+                waveSpheres += LanesSet( isSphere );
+            }
+            leaf = kInnerNode;
+            continue;
+        }
+
+        const uint32_t started = static_cast< uint32_t >( __popcll( mTrav ) );
+        for ( int burst = 0; burst < kTraverseBurst; ++burst )
+        {
+            const bool go = node != end && leaf == kInnerNode;
+            const uint32_t active = static_cast< uint32_t >( __popcll( Ballot( node != end ) & Ballot( leaf == kInnerNode ) ) );
+            if ( burst && 2 * active < started ) break;
+            waveNodes += active;
+            waveSteps++;
+            if ( go )
+            {
+                float4 r;
+                uint32_t second = node + 1u; // below the top: the first child of an inner node, the successor of a leaf
+                if ( node < topCount )
+                {
+                    r      = LoadLds16( topLds + node );
+                    second = topWords[node];
+                }
+                else
+                    r = Load16( nodes, 16u * node );
+                const uint32_t x = __float_as_uint( r.x ), y = __float_as_uint( r.y ), word = __float_as_uint( r.w );
+                const bool inside = ( ( cell & 0xFFFFu ) - ( x & 0xFFFFu ) <= ( x >> 16 ) ) & ( ( cell >> 16 ) - ( y & 0xFFFFu ) <= ( y >> 16 ) ) & ( r.z > pw );
+                const bool isLeaf = ( word & kLeafFlag ) != 0;
+                node = ( isLeaf | inside ) ? second : word;
+                if ( isLeaf & inside ) leaf = word & ~kLeafFlag;
+            }
+        }
+    }
+    FlushWaveCounter( stats, ST_RAYS_SHADOW, waveRays );
+    FlushWaveCounter( stats, ST_NODES_SHADOW, waveNodes );
+    FlushWaveCounter( stats, ST_TRI_SHADOW, waveTris );
+    FlushWaveCounter( stats, ST_SPH_SHADOW, waveSpheres );
+    FlushWaveCounter( stats, ST_STEPS_SHADOW, waveSteps );
+}
+
 // ------------------------------------------------------------------------------------------------ shading
 
 // What the light loop and the BRDF sampling need from a shaded hit
@@ -1656,7 +1818,11 @@ void LaunchShade( const LaunchCfg& cfg, const SceneView& sv, const RngParams& rn
 void LaunchConnect( const LaunchCfg& cfg, const SceneView& sv, const PathBuffers& pb, int bounce, uint64_t* stats )
 {
     const dim3 grid( cfg.connectBlocks ), block( kConnectBlock );
-    if ( pb.directSum )
+    if ( cfg.ordered && sv.shadowNodes && pb.directSum )
+        hipLaunchKernelGGL( ( ConnectParallelKernel< true > ), grid, block, 0, cfg.stream, sv, pb, bounce, stats );
+    else if ( cfg.ordered && sv.shadowNodes )
+        hipLaunchKernelGGL( ( ConnectParallelKernel< false > ), grid, block, 0, cfg.stream, sv, pb, bounce, stats );
+    else if ( pb.directSum )
         hipLaunchKernelGGL( ( ConnectKernel< true, false > ), grid, block, 0, cfg.stream, sv, pb, bounce, stats );
     else
         hipLaunchKernelGGL( ( ConnectKernel< false, false > ), grid, block, 0, cfg.stream, sv, pb, bounce, stats );

@@ -4,8 +4,11 @@
 //   nodes      2 x float4 per node (32 B): {lo.x, lo.y, hi.x, hi.y} {lo.z, hi.z, link, word}; link = node to go to after
 //              this node's subtree (top bit: leaf), word = leaf descriptor or first child.  The first numTopNodes
 //              nodes are the top of the tree (sibling pairs, largest parent box first), the rest follows in the reference's pre-order
-//   prims      4 x float4 per primitive (48 B used, 64 B apart = one cache line): triangle {v0, tag 0} {v1 - v0} {v2 - v0};
-//              sphere {centre, tag 1} {radius, sphere index}
+//   prims      4 x float4 per primitive (64 B = one cache line): triangle {v0, tag 0} {v1 - v0, lo.x} {v2 - v0, lo.y}
+//              {lo.z, hi.xyz}; sphere {centre, tag 1} {radius, sphere index, -, lo.x} {-, -, -, lo.y} {lo.z, hi.xyz};
+//              lo / hi = the box of the BVH leaf that holds the primitive
+//   shadowNodes  1 x float4 per record, for the shadow rays of a scene lit by one directional light (see
+//              ConnectParallelKernel in kernels.hip), or absent
 //   triShade   8 x float4 per triangle primitive (112 B used, 128 B apart = one L2 line): n0 n1 n2 t0 t1 t2 uv0 uv1 uv2 material
 //   spheres    6 x float4: world-to-local columns 0..3, {centre, radius}, {material}
 //   materials  2 x float4: {albedo, texture index} {Ke}
@@ -24,6 +27,7 @@ constexpr uint32_t kLeafFlag     = 0x80000000u; // top bit of a node's link word
 constexpr uint32_t kTopNodes     = 4095;          // default size of the top of the tree that is stored first
 constexpr uint32_t kLeafFirstMask = 0x0FFFFFFFu; // leaf word: low 28 bits first primitive, high 4 bits count - 1
 constexpr int kMaxLeafShapes     = 16;
+constexpr uint32_t kShadowTopNodes = 3840;       // records at the front of shadowNodes that the kernel keeps in LDS (20 bytes each)
 // nodes and primitive records are read through 32-bit-offset buffer descriptors: each array stays under 4 GiB
 constexpr uint32_t kMaxNodes = 0x7FFFFFFFu / 32u - 1u;
 constexpr uint32_t kMaxPrims = 0xFFFFFFFFu / 64u - 1u;
@@ -58,6 +62,11 @@ struct SceneView
 {
     const float4* nodes;
     const float4* orderedNodes; // second layout for front-to-back traversal: 4 x float4 per node, or nullptr
+    const float4* shadowNodes;  // third layout, in the space of the one directional light: 1 x float4 per record, or nullptr
+    const uint32_t* shadowTopWords; // second word of the first numShadowTop records
+    uint32_t numShadowNodes, numShadowTop;
+    float lightU[3], lightV[3], lightW[3]; // shadowNodes: axes across the light's direction, and the direction towards the light
+    float shadowOrigin[2], shadowInvCell[2]; // shadowNodes: grid coordinate along u = ( dot( p, lightU ) - shadowOrigin[0] ) * shadowInvCell[0]
     const float4* prims;
     const float4* triShade;
     const float4* spheres;
