@@ -92,6 +92,7 @@ def main():
 
     import torch
     from pathtracer_amd import abi, api, host, path_tracer
+    from pathtracer_amd.scene import _from_ptr
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (there is no CPU fallback for the hot path)")
@@ -209,7 +210,8 @@ def main():
         node_bytes = 36 if ordered else 32
         bytes_closest = node_bytes * mine["nodes_closest"] + 48 * mine["tri_tests_closest"] + 84 * mine["sphere_tests_closest"] + 48 * mine["rays_closest"]
         # shadow rays of a scene lit by one directional light read 16-byte records in the light's frame (front-to-back mode)
-        light_space = ordered and desc.num_lights == 1 and desc.lights[0].type == abi.PT_LIGHT_DIRECTIONAL and not (desc.flags & abi.PT_SCENE_NO_PARALLEL_SHADOWS)
+        one_directional = desc.num_lights == 1 and int(_from_ptr(desc.lights, 1, abi.LIGHT_DTYPE)["type"][0]) == abi.PT_LIGHT_DIRECTIONAL
+        light_space = ordered and one_directional and not (desc.flags & abi.PT_SCENE_NO_PARALLEL_SHADOWS)
         bytes_shadow = (16 if light_space else 32) * mine["nodes_shadow"] + 48 * mine["tri_tests_shadow"] + 16 * mine["sphere_tests_shadow"] + 36 * mine["rays_shadow"]
         # records of the scene the kernel reads at least once (device sizes), beside the rays in and the results out
         scene_bytes = int(desc.num_nodes) * (64 if ordered else 32) + int(desc.num_prims) * 64
