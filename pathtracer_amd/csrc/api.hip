@@ -174,6 +174,56 @@ void ParallelFor( uint64_t n, const Body& body )
     for ( std::thread& t : pool ) t.join();
 }
 
+// The tree cut into its top and the subtrees below it, for passes in which a node depends on its parent or on its
+// children only: the nodes of a subtree are a contiguous range [root, escape[root]) of the reference's pre-order,
+// parents before children.  `upper` (ascending: a parent's index is below its children's) is split largest subtree first.
+struct TreeCut
+{
+    std::vector< uint32_t > upper, roots;
+};
+
+TreeCut CutTree( const PtSceneDesc* d, const std::vector< uint32_t >& escape )
+{
+    TreeCut cut;
+    const uint32_t N = static_cast< uint32_t >( d->num_nodes );
+    std::priority_queue< std::pair< uint32_t, uint32_t > > open; // (nodes in the subtree, its root)
+    open.push( { N, 0u } );
+    while ( !open.empty() && open.size() + cut.roots.size() < 1024 )
+    {
+        const uint32_t size = open.top().first, x = open.top().second;
+        open.pop();
+        if ( d->nodes[x].num_shapes > 0 || size < 8192 )
+        {
+            cut.roots.push_back( x );
+            continue;
+        }
+        cut.upper.push_back( x );
+        const uint32_t a = x + 1, b = static_cast< uint32_t >( d->nodes[x].offset );
+        open.push( { escape[a] - a, a } );
+        open.push( { escape[b] - b, b } );
+    }
+    for ( ; !open.empty(); open.pop() ) cut.roots.push_back( open.top().second );
+    std::sort( cut.upper.begin(), cut.upper.end() );
+    return cut;
+}
+
+// body( root ) for every subtree of the cut, on several host threads when the tree is large
+template < typename Body >
+void ForEachSubtree( const TreeCut& cut, uint64_t numNodes, const Body& body )
+{
+    std::atomic< size_t > next{ 0 };
+    auto work = [&] {
+        for ( size_t k = next.fetch_add( 1 ); k < cut.roots.size(); k = next.fetch_add( 1 ) ) body( cut.roots[k] );
+    };
+    unsigned threads = std::thread::hardware_concurrency();
+    if ( threads > 16 ) threads = 16;
+    if ( numNodes < ( 1u << 18 ) || threads < 2 ) threads = 1;
+    std::vector< std::thread > pool;
+    for ( unsigned t = 1; t < threads; ++t ) pool.emplace_back( work );
+    work();
+    for ( std::thread& t : pool ) t.join();
+}
+
 } // namespace
 
 struct PtScene
@@ -468,52 +518,19 @@ int Upload( PtScene* s, const PtSceneDesc* d, const std::vector< uint32_t >& esc
                 ( secondIsNear ? ra : rb )[8 + o] = r[8 + o];                      // after the far child's: what follows the parent
             }
         };
-        // The nodes of a subtree are a contiguous range of the reference's pre-order, parents before children, and
-        // depend on nothing outside it but the subtree root's parent.  The top of the tree is filled first, largest
-        // subtree split first, then the subtrees below it side by side.
-        std::vector< uint32_t > upper, roots;
-        {
-            std::priority_queue< std::pair< uint32_t, uint32_t > > open; // (nodes in the subtree, its root)
-            open.push( { N, 0u } );
-            while ( !open.empty() && open.size() + roots.size() < 1024 )
-            {
-                const uint32_t size = open.top().first, x = open.top().second;
-                open.pop();
-                if ( d->nodes[x].num_shapes > 0 || size < 8192 )
-                {
-                    roots.push_back( x );
-                    continue;
-                }
-                upper.push_back( x );
-                const uint32_t a = x + 1, b = static_cast< uint32_t >( d->nodes[x].offset );
-                open.push( { escape[a] - a, a } );
-                open.push( { escape[b] - b, b } );
-            }
-            for ( ; !open.empty(); open.pop() ) roots.push_back( open.top().second );
-            std::sort( upper.begin(), upper.end() ); // a parent's index is below its children's
-        }
-        for ( uint32_t x : upper ) fill( x );
-        {
-            std::atomic< size_t > nextRoot{ 0 };
-            auto work = [&] {
-                for ( size_t k = nextRoot.fetch_add( 1 ); k < roots.size(); k = nextRoot.fetch_add( 1 ) )
-                    for ( uint32_t i = roots[k], end = escape[roots[k]]; i < end; ++i ) fill( i );
-            };
-            unsigned threads = std::thread::hardware_concurrency();
-            if ( threads > 16 ) threads = 16;
-            if ( N < ( 1u << 18 ) || threads < 2 ) threads = 1;
-            std::vector< std::thread > pool;
-            for ( unsigned t = 1; t < threads; ++t ) pool.emplace_back( work );
-            work();
-            for ( std::thread& t : pool ) t.join();
-        }
+        // top of the tree first (a node's links derive from its parent's), then the subtrees below it side by side
+        const TreeCut cut = CutTree( d, escape );
+        for ( uint32_t x : cut.upper ) fill( x );
+        ForEachSubtree( cut, N, [&]( uint32_t root ) {
+            for ( uint32_t i = root, end = escape[root]; i < end; ++i ) fill( i );
+        } );
         HIP_TRY( s->orderedNodes.Upload( rec.get(), 64ull * numOrdered ) );
     }
 
     // Third layout, for the shadow rays of a scene whose one light is directional (kernels.hip, ConnectParallelKernel):
     // every such ray has the light's direction, so in a frame with one axis along it a node's box is a rectangle and
     // one depth.  16-byte records {x0 | width << 16, y0 | height << 16, wmax, word}: the rectangle on a 16-bit grid
-    // over the root's, rounded outwards with cells to spare for the rounding of the ray's own projection; wmax
+    // over the root's, widened by what the rounding of the ray's own projection can amount to; wmax
     // the largest depth (towards the light) of the box, rounded up.  The records are outer bounds only: a hit
     // found through them counts once the reference's own test of its leaf's box has passed (the box travels in the
     // primitive record).  Order: the first numShadowTop records are the top of the tree (as in the other layouts) and
@@ -561,36 +578,90 @@ int Upload( PtScene* s, const PtSceneDesc* d, const std::vector< uint32_t >& esc
         double maxAbs = 0;
         for ( int a = 0; a < 3; ++a ) maxAbs = std::max( { maxAbs, std::fabs( static_cast< double >( d->nodes[0].aabb_min[a] ) ), std::fabs( static_cast< double >( d->nodes[0].aabb_max[a] ) ) } );
         const double projectionError = zeros == 2 ? 0.0 : std::ldexp( maxAbs, -20 );
-        auto project = [&]( const PtBvhNode& n, const float* axis, double* lo, double* hi ) {
-            *lo = std::numeric_limits< double >::infinity();
-            *hi = -*lo;
-            for ( int c = 0; c < 8; ++c )
+        // Bounds of every node in the light's frame, from the geometry below it rather than from its box (the rectangle
+        // around a box seen at an angle is far larger than the one around its triangles): leaves from their primitives,
+        // inner nodes from their children, children before parents.  {u0, u1, v0, v1, w1} per node, rounded outwards.
+        std::unique_ptr< float[] > frame( build ? new float[5ull * N] : nullptr );
+        auto down = []( double x ) { float f = static_cast< float >( x ); return static_cast< double >( f ) > x ? std::nextafter( f, -std::numeric_limits< float >::infinity() ) : f; };
+        auto up   = []( double x ) { float f = static_cast< float >( x ); return static_cast< double >( f ) < x ? std::nextafter( f, std::numeric_limits< float >::infinity() ) : f; };
+        auto bound = [&]( uint32_t i ) {
+            const PtBvhNode& n = d->nodes[i];
+            float* f = &frame[5ull * i];
+            if ( n.num_shapes == 0 )
             {
-                const double x = c & 1 ? n.aabb_max[0] : n.aabb_min[0], y = c & 2 ? n.aabb_max[1] : n.aabb_min[1], z = c & 4 ? n.aabb_max[2] : n.aabb_min[2];
-                const double p = x * axis[0] + y * axis[1] + z * axis[2];
-                *lo = std::min( *lo, p );
-                *hi = std::max( *hi, p );
+                const float *x = &frame[5ull * ( i + 1 )], *y = &frame[5ull * static_cast< uint32_t >( n.offset )];
+                f[0] = std::min( x[0], y[0] ); f[1] = std::max( x[1], y[1] );
+                f[2] = std::min( x[2], y[2] ); f[3] = std::max( x[3], y[3] );
+                f[4] = std::max( x[4], y[4] );
+                return;
             }
+            const double inf = std::numeric_limits< double >::infinity();
+            double lo[3] = { inf, inf, inf }, hi[3] = { -inf, -inf, -inf };
+            const float* axes[3] = { fu, fv, fw };
+            for ( uint32_t k = 0; k < n.num_shapes; ++k )
+            {
+                const PtPrim& prim = d->prims[static_cast< uint64_t >( n.offset ) + k];
+                if ( prim.type == PT_PRIM_TRIANGLE )
+                {
+                    const PtTriangle& t = d->triangles[prim.index];
+                    const uint32_t idx[3] = { t.i0, t.i1, t.i2 };
+                    for ( int c = 0; c < 3; ++c )
+                    {
+                        const float* p = TriVertex( d, d->vertices, t, idx[c], 3 );
+                        for ( int a = 0; a < 3; ++a )
+                        {
+                            const double q = static_cast< double >( p[0] ) * axes[a][0] + static_cast< double >( p[1] ) * axes[a][1] + static_cast< double >( p[2] ) * axes[a][2];
+                            lo[a] = std::min( lo[a], q );
+                            hi[a] = std::max( hi[a], q );
+                        }
+                    }
+                }
+                else
+                {
+                    const PtSphere& sp = d->spheres[prim.index];
+                    for ( int a = 0; a < 3; ++a )
+                    {
+                        const double q = static_cast< double >( sp.position[0] ) * axes[a][0] + static_cast< double >( sp.position[1] ) * axes[a][1] + static_cast< double >( sp.position[2] ) * axes[a][2];
+                        const double len = std::sqrt( static_cast< double >( axes[a][0] ) * axes[a][0] + static_cast< double >( axes[a][1] ) * axes[a][1] + static_cast< double >( axes[a][2] ) * axes[a][2] );
+                        const double r = std::fabs( static_cast< double >( sp.radius ) ) * len * ( 1.0 + 1e-6 );
+                        lo[a] = std::min( lo[a], q - r );
+                        hi[a] = std::max( hi[a], q + r );
+                    }
+                }
+            }
+            f[0] = down( lo[0] ); f[1] = up( hi[0] );
+            f[2] = down( lo[1] ); f[3] = up( hi[1] );
+            f[4] = up( hi[2] );
         };
+        if ( build )
+        {
+            const TreeCut cut = CutTree( d, escape );
+            ForEachSubtree( cut, N, [&]( uint32_t root ) {
+                for ( uint32_t i = escape[root]; i-- > root; ) bound( i );
+            } );
+            for ( size_t k = cut.upper.size(); k-- > 0; ) bound( cut.upper[k] );
+        }
         double origin[2] = { 0, 0 }, cell[2] = { 1, 1 };
         float invCell[2] = { 1, 1 }, originF[2] = { 0, 0 };
-        int slack[2] = { 2, 2 };
+        double slack[2] = { 1, 1 }; // in cells
         for ( int a = 0; a < 2 && build; ++a )
         {
-            double lo, hi;
-            project( d->nodes[0], a == 0 ? fu : fv, &lo, &hi );
+            const double lo = frame[2 * a], hi = frame[2 * a + 1]; // the root's
             build = std::isfinite( lo ) && std::isfinite( hi );
             if ( !build ) break;
             cell[a]    = std::max( { ( hi - lo ) / 64000.0, std::ldexp( maxAbs, -18 ), 1e-30 } );
             invCell[a] = static_cast< float >( 1.0 / cell[a] );
             cell[a]    = 1.0 / static_cast< double >( invCell[a] ); // the cell the device's multiplication implies
-            // the device computes floor( ( p - origin ) * invCell ) in single precision: its p is off by projectionError,
-            // the subtraction and the product by a few ulps of a number below 2^16
-            const int need = 2 + static_cast< int >( std::ceil( projectionError / cell[a] ) );
-            slack[a]   = need;
-            originF[a] = static_cast< float >( lo - ( need + 2 ) * cell[a] );
+            // The device computes floor( ( p - origin ) * invCell ) in single precision.  Its p is off by projectionError, the
+            // subtraction by an ulp of a number of the scene's size (at most 1 / 8 of a cell, see the cell's floor above),
+            // the product by an ulp of a number below 2^16; and a ray that the reference's test counts as a hit may pass
+            // a rounding error outside the triangle.  A cell q then covers every point the device maps to q if the
+            // rectangle [lo, hi] is widened by `slack` cells before it is rounded to cells.
+            slack[a]   = ( projectionError + std::ldexp( maxAbs, -21 ) ) / cell[a] + 0.1;
+            const int border = 2 + static_cast< int >( std::ceil( slack[a] ) );
+            originF[a] = static_cast< float >( lo - border * cell[a] );
             origin[a]  = originF[a];
-            build      = std::isfinite( originF[a] ) && std::isfinite( invCell[a] ) && ( hi - origin[a] ) / cell[a] + need + 2 < 65534.0;
+            build      = std::isfinite( originF[a] ) && std::isfinite( invCell[a] ) && ( hi - origin[a] ) / cell[a] + border < 65534.0;
         }
         if ( build )
         {
@@ -615,17 +686,15 @@ int Upload( PtScene* s, const PtSceneDesc* d, const std::vector< uint32_t >& esc
                 {
                     const PtBvhNode& n = d->nodes[i];
                     uint32_t q[2];
+                    const float* f = &frame[5ull * i];
                     for ( int a = 0; a < 2; ++a )
                     {
-                        double lo, hi;
-                        project( n, a == 0 ? fu : fv, &lo, &hi );
-                        const double qlo = std::min( 65534.0, std::max( 1.0, std::floor( ( lo - origin[a] ) / cell[a] ) - slack[a] ) );
-                        const double qhi = std::min( 65534.0, std::max( qlo, std::ceil( ( hi - origin[a] ) / cell[a] ) + slack[a] ) );
+                        const double lo = f[2 * a], hi = f[2 * a + 1];
+                        const double qlo = std::min( 65534.0, std::max( 1.0, std::floor( ( lo - origin[a] ) / cell[a] - slack[a] ) ) );
+                        const double qhi = std::min( 65534.0, std::max( qlo, std::floor( ( hi - origin[a] ) / cell[a] + slack[a] ) ) );
                         q[a] = static_cast< uint32_t >( qlo ) | static_cast< uint32_t >( qhi - qlo ) << 16;
                     }
-                    double wlo, whi;
-                    project( n, fw, &wlo, &whi );
-                    whi += projectionError;
+                    const double whi = static_cast< double >( f[4] ) + projectionError;
                     float wmax = static_cast< float >( whi );
                     if ( static_cast< double >( wmax ) < whi ) wmax = std::nextafter( wmax, std::numeric_limits< float >::infinity() );
                     const bool leaf     = n.num_shapes > 0;

@@ -1798,7 +1798,8 @@ void LaunchExtend( const LaunchCfg& cfg, const SceneView& sv, const PathBuffers&
         hipLaunchKernelGGL( ( ExtendKernel< false, true > ), grid, block, 0, cfg.stream, sv, pb, bounce, numPaths, stats );
     else
         hipLaunchKernelGGL( ( ExtendKernel< false, false > ), grid, block, 0, cfg.stream, sv, pb, bounce, numPaths, stats );
-    if ( cfg.ordered ) hipLaunchKernelGGL( RedoKernel, dim3( 256 ), dim3( kBlock ), 0, cfg.stream, sv, pb, bounce, stats );
+    // one thread per ambiguous ray where the grid reaches (its length is known on the device only); a thread's rays run one after the other
+    if ( cfg.ordered ) hipLaunchKernelGGL( RedoKernel, dim3( cfg.blocks > 256 ? cfg.blocks : 256 ), dim3( kBlock ), 0, cfg.stream, sv, pb, bounce, stats );
 }
 
 void LaunchShade( const LaunchCfg& cfg, const SceneView& sv, const RngParams& rng, const PathBuffers& pb, int bounce, int maxDepth,

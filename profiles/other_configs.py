@@ -38,7 +38,9 @@ def measure(name, desc, spp, repeats=3, ordered=True, flags=0):
             "mrays_per_s": round(rays / best.render_ms * 1e-3, 1),
             "msamples_per_s": round(best.samples / best.render_ms * 1e-3, 1),
             "extend_ms": round(best.kernel_ms[1], 3), "shade_ms": round(best.kernel_ms[2], 3), "connect_ms": round(best.kernel_ms[3], 3),
-            "rays_redone": int(best.rays_redone), "upload_s": round(t_upload, 3),
+            "rays_redone": int(best.rays_redone), "shadow_rays": int(best.rays_shadow),
+            "nodes_per_shadow_ray": round(best.nodes_shadow / max(1, best.rays_shadow), 2),
+            "tests_per_shadow_ray": round((best.tri_tests_shadow + best.sphere_tests_shadow) / max(1, best.rays_shadow), 3), "upload_s": round(t_upload, 3),
             "nodes_per_ray": round((best.nodes_closest + best.nodes_shadow) / rays, 2),
             "prim_tests_per_ray": round((best.tri_tests_closest + best.tri_tests_shadow + best.sphere_tests_closest
                                          + best.sphere_tests_shadow) / rays, 3),
