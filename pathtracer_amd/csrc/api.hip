@@ -528,10 +528,11 @@ int Upload( PtScene* s, const PtSceneDesc* d, const std::vector< uint32_t >& esc
     }
 
     // Third layout, for the shadow rays of a scene whose one light is directional (kernels.hip, ConnectParallelKernel):
-    // every such ray has the light's direction, so in a frame with one axis along it a node's box is a rectangle and
-    // one depth.  16-byte records {x0 | width << 16, y0 | height << 16, wmax, word}: the rectangle on a 16-bit grid
-    // over the root's, widened by what the rounding of the ray's own projection can amount to; wmax
-    // the largest depth (towards the light) of the box, rounded up.  The records are outer bounds only: a hit
+    // every such ray has the light's direction, so seen along it a node is a rectangle, and the ray can only enter the
+    // node if its point lies in the rectangle and the node reaches beyond the ray's start.  16-byte records
+    // {x0 | width << 16, y0 | height << 16, far, word}: the rectangle on a 16-bit grid over the root's, widened by what
+    // the rounding of the ray's own projection can amount to; far = the box's far plane, in the rays' sense, along the
+    // world axis they mostly travel on.  The records are outer bounds only: a hit
     // found through them counts once the reference's own test of its leaf's box has passed (the box travels in the
     // primitive record).  Order: the first numShadowTop records are the top of the tree (as in the other layouts) and
     // are read from LDS with a second word each; the rest follows in the reference's pre-order, where an inner
@@ -545,9 +546,12 @@ int Upload( PtScene* s, const PtSceneDesc* d, const std::vector< uint32_t >& esc
         const double w[3] = { -static_cast< double >( d->lights[0].direction[0] ), -static_cast< double >( d->lights[0].direction[1] ),
                               -static_cast< double >( d->lights[0].direction[2] ) }; // wi of src/lights.cpp:30
         const double wLen = std::sqrt( w[0] * w[0] + w[1] * w[1] + w[2] * w[2] );
-        float fu[3] = { 0, 0, 0 }, fv[3] = { 0, 0, 0 }, fw[3] = { static_cast< float >( w[0] ), static_cast< float >( w[1] ), static_cast< float >( w[2] ) };
+        float fu[3] = { 0, 0, 0 }, fv[3] = { 0, 0, 0 };
         const int zeros = ( w[0] == 0 ) + ( w[1] == 0 ) + ( w[2] == 0 );
         bool build = std::isfinite( wLen ) && wLen > 0;
+        int depthAxis = 0; // the world axis the rays mostly travel along
+        for ( int a = 1; a < 3; ++a )
+            if ( std::fabs( w[a] ) > std::fabs( w[depthAxis] ) ) depthAxis = a;
         // a record's word keeps bit 31 for the leaf flag, which leaves three bits for a leaf's shape count
         for ( uint32_t i = 0; i < N && build; ++i ) build = d->nodes[i].num_shapes <= 8;
         if ( build && zeros == 2 )
@@ -580,24 +584,23 @@ int Upload( PtScene* s, const PtSceneDesc* d, const std::vector< uint32_t >& esc
         const double projectionError = zeros == 2 ? 0.0 : std::ldexp( maxAbs, -20 );
         // Bounds of every node in the light's frame, from the geometry below it rather than from its box (the rectangle
         // around a box seen at an angle is far larger than the one around its triangles): leaves from their primitives,
-        // inner nodes from their children, children before parents.  {u0, u1, v0, v1, w1} per node, rounded outwards.
-        std::unique_ptr< float[] > frame( build ? new float[5ull * N] : nullptr );
+        // inner nodes from their children, children before parents.  {u0, u1, v0, v1} per node, rounded outwards.
+        std::unique_ptr< float[] > frame( build ? new float[4ull * N] : nullptr );
         auto down = []( double x ) { float f = static_cast< float >( x ); return static_cast< double >( f ) > x ? std::nextafter( f, -std::numeric_limits< float >::infinity() ) : f; };
         auto up   = []( double x ) { float f = static_cast< float >( x ); return static_cast< double >( f ) < x ? std::nextafter( f, std::numeric_limits< float >::infinity() ) : f; };
         auto bound = [&]( uint32_t i ) {
             const PtBvhNode& n = d->nodes[i];
-            float* f = &frame[5ull * i];
+            float* f = &frame[4ull * i];
             if ( n.num_shapes == 0 )
             {
-                const float *x = &frame[5ull * ( i + 1 )], *y = &frame[5ull * static_cast< uint32_t >( n.offset )];
+                const float *x = &frame[4ull * ( i + 1 )], *y = &frame[4ull * static_cast< uint32_t >( n.offset )];
                 f[0] = std::min( x[0], y[0] ); f[1] = std::max( x[1], y[1] );
                 f[2] = std::min( x[2], y[2] ); f[3] = std::max( x[3], y[3] );
-                f[4] = std::max( x[4], y[4] );
                 return;
             }
             const double inf = std::numeric_limits< double >::infinity();
-            double lo[3] = { inf, inf, inf }, hi[3] = { -inf, -inf, -inf };
-            const float* axes[3] = { fu, fv, fw };
+            double lo[2] = { inf, inf }, hi[2] = { -inf, -inf };
+            const float* axes[2] = { fu, fv };
             for ( uint32_t k = 0; k < n.num_shapes; ++k )
             {
                 const PtPrim& prim = d->prims[static_cast< uint64_t >( n.offset ) + k];
@@ -608,7 +611,7 @@ int Upload( PtScene* s, const PtSceneDesc* d, const std::vector< uint32_t >& esc
                     for ( int c = 0; c < 3; ++c )
                     {
                         const float* p = TriVertex( d, d->vertices, t, idx[c], 3 );
-                        for ( int a = 0; a < 3; ++a )
+                        for ( int a = 0; a < 2; ++a )
                         {
                             const double q = static_cast< double >( p[0] ) * axes[a][0] + static_cast< double >( p[1] ) * axes[a][1] + static_cast< double >( p[2] ) * axes[a][2];
                             lo[a] = std::min( lo[a], q );
@@ -619,7 +622,7 @@ int Upload( PtScene* s, const PtSceneDesc* d, const std::vector< uint32_t >& esc
                 else
                 {
                     const PtSphere& sp = d->spheres[prim.index];
-                    for ( int a = 0; a < 3; ++a )
+                    for ( int a = 0; a < 2; ++a )
                     {
                         const double q = static_cast< double >( sp.position[0] ) * axes[a][0] + static_cast< double >( sp.position[1] ) * axes[a][1] + static_cast< double >( sp.position[2] ) * axes[a][2];
                         const double len = std::sqrt( static_cast< double >( axes[a][0] ) * axes[a][0] + static_cast< double >( axes[a][1] ) * axes[a][1] + static_cast< double >( axes[a][2] ) * axes[a][2] );
@@ -631,7 +634,6 @@ int Upload( PtScene* s, const PtSceneDesc* d, const std::vector< uint32_t >& esc
             }
             f[0] = down( lo[0] ); f[1] = up( hi[0] );
             f[2] = down( lo[1] ); f[3] = up( hi[1] );
-            f[4] = up( hi[2] );
         };
         if ( build )
         {
@@ -686,7 +688,7 @@ int Upload( PtScene* s, const PtSceneDesc* d, const std::vector< uint32_t >& esc
                 {
                     const PtBvhNode& n = d->nodes[i];
                     uint32_t q[2];
-                    const float* f = &frame[5ull * i];
+                    const float* f = &frame[4ull * i];
                     for ( int a = 0; a < 2; ++a )
                     {
                         const double lo = f[2 * a], hi = f[2 * a + 1];
@@ -694,9 +696,9 @@ int Upload( PtScene* s, const PtSceneDesc* d, const std::vector< uint32_t >& esc
                         const double qhi = std::min( 65534.0, std::max( qlo, std::floor( ( hi - origin[a] ) / cell[a] + slack[a] ) ) );
                         q[a] = static_cast< uint32_t >( qlo ) | static_cast< uint32_t >( qhi - qlo ) << 16;
                     }
-                    const double whi = static_cast< double >( f[4] ) + projectionError;
-                    float wmax = static_cast< float >( whi );
-                    if ( static_cast< double >( wmax ) < whi ) wmax = std::nextafter( wmax, std::numeric_limits< float >::infinity() );
+                    // how far the box reaches in the rays' sense along the world axis they mostly travel on: its far
+                    // plane there, which is the reference's own "the box lies ahead of the ray" test on that axis, and exact
+                    const float wmax = w[depthAxis] > 0 ? n.aabb_max[depthAxis] : -n.aabb_min[depthAxis];
                     const bool leaf     = n.num_shapes > 0;
                     const uint32_t link = sp[escape[i]];
                     const uint32_t word = leaf ? kLeafFlag | static_cast< uint32_t >( n.offset ) | ( static_cast< uint32_t >( n.num_shapes - 1 ) << 28 ) : link;
@@ -723,13 +725,14 @@ int Upload( PtScene* s, const PtSceneDesc* d, const std::vector< uint32_t >& esc
             {
                 s->view.lightU[a] = fu[a];
                 s->view.lightV[a] = fv[a];
-                s->view.lightW[a] = fw[a];
             }
             for ( int a = 0; a < 2; ++a )
             {
                 s->view.shadowOrigin[a]  = originF[a];
                 s->view.shadowInvCell[a] = invCell[a];
             }
+            s->view.shadowDepthAxis = static_cast< uint32_t >( depthAxis );
+            s->view.shadowDepthSign = w[depthAxis] < 0 ? -1.0f : 1.0f;
         }
     }
 

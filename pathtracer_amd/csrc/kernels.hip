@@ -1170,16 +1170,17 @@ __global__ __launch_bounds__( kConnectBlock ) PT_CONNECT_OCCUPANCY void ConnectK
 }
 
 // Shadow rays of a scene lit by one directional light (src/lights.cpp:25-38): they all have the light's direction,
-// so BVH::Occluded (src/bvh.cpp:270-310) becomes a search in two dimensions.  In the light's frame - lightU and lightV
-// across the direction, lightW along it, towards the light - a ray is a point (u, v) and a depth w, a node's box a
-// rectangle and the depth range it covers, and the box can only be entered if the point lies in the rectangle and the
-// box reaches beyond the ray's depth.  The records of the third node layout (api.hip) hold exactly that, as an outer
+// so BVH::Occluded (src/bvh.cpp:270-310) becomes a search in two dimensions.  Seen along the light's direction - lightU
+// and lightV are two axes across it - a ray is a point, a node the rectangle around its geometry, and the node can
+// only be entered if the point lies in the rectangle and the node's box reaches beyond the ray's start: its far plane
+// along the world axis the rays mostly travel on lies ahead of the origin (the reference's own test on that axis).  The
+// records of the third node layout (api.hip) hold exactly that, as an outer
 // bound: 16 bytes per node visit instead of 32, four integer compares and a float compare instead of the slab
 // arithmetic, and no per-ray reciprocal.  Being outer bounds, they may lead to a primitive that the reference's
 // descent never reaches; the answer stays the reference's because a hit only counts if the reference's test of the
 // primitive's leaf box passes (with it, the boxes being nested, those of all its ancestors): any-hit asks whether SOME
 // primitive that the reference can reach is hit, and the order of the search does not matter.
-// State per lane: the point as two grid cells, the depth, and the origin for the primitive tests.
+// State per lane: the point as two grid cells, the start along that axis, and the origin for the primitive tests.
 // (Two rays per lane, to have twice the loads in flight: 31.2 ms against 24.7 per 32 samples per pixel of the
 // benchmark's frame - the kernel does not wait for single loads but for the memory pipeline as a whole.)
 template < bool kDirectSum >
@@ -1204,11 +1205,11 @@ __global__ __launch_bounds__( kConnectBlock ) PT_CONNECT_OCCUPANCY void ConnectP
     const f3 inv  = F3( 1.0f / d.x, 1.0f / d.y, 1.0f / d.z ); // bvh.cpp:275-276
     const bool nx = inv.x < 0, ny = inv.y < 0, nz = inv.z < 0;
     constexpr float tMax = FLT_MAX;                            // src/lights.cpp:35
-    const f3 axisU = F3( sv.lightU ), axisV = F3( sv.lightV ), axisW = F3( sv.lightW );
+    const f3 axisU = F3( sv.lightU ), axisV = F3( sv.lightV );
     uint32_t rec = kNoRay, node = end, leaf = kInnerNode;
     f3 o = F3( 0.0f, 0.0f, 0.0f );
     uint32_t cell = 0; // the ray's point: its grid cell along u in the low half, along v in the high half
-    float pw = 0.0f;   // the ray's depth
+    float pw = 0.0f;   // where the ray starts on the world axis the rays mostly travel along, in their sense
     bool occluded = false;
     uint32_t waveRays = 0, waveNodes = 0, waveTris = 0, waveSpheres = 0, waveSteps = 0; // whole-wave totals, wave-uniform
 
@@ -1256,7 +1257,7 @@ __global__ __launch_bounds__( kConnectBlock ) PT_CONNECT_OCCUPANCY void ConnectP
                     const float gv = ( Dot( o, axisV ) - sv.shadowOrigin[1] ) * sv.shadowInvCell[1];
                     cell = static_cast< uint32_t >( __builtin_fminf( __builtin_fmaxf( gu, 0.0f ), 65535.0f ) ) |
                            static_cast< uint32_t >( __builtin_fminf( __builtin_fmaxf( gv, 0.0f ), 65535.0f ) ) << 16;
-                    pw = Dot( o, axisW );
+                    pw = ( sv.shadowDepthAxis == 0 ? o.x : sv.shadowDepthAxis == 1 ? o.y : o.z ) * sv.shadowDepthSign;
                     occluded = false;
                     node     = 0;
                 }

@@ -65,8 +65,10 @@ struct SceneView
     const float4* shadowNodes;  // third layout, in the space of the one directional light: 1 x float4 per record, or nullptr
     const uint32_t* shadowTopWords; // second word of the first numShadowTop records
     uint32_t numShadowNodes, numShadowTop;
-    float lightU[3], lightV[3], lightW[3]; // shadowNodes: axes across the light's direction, and the direction towards the light
+    float lightU[3], lightV[3]; // shadowNodes: two axes across the light's direction
     float shadowOrigin[2], shadowInvCell[2]; // shadowNodes: grid coordinate along u = ( dot( p, lightU ) - shadowOrigin[0] ) * shadowInvCell[0]
+    uint32_t shadowDepthAxis;   // shadowNodes: the world axis the rays mostly travel along; a record's third word is the box's far plane
+    float shadowDepthSign;      // there in the rays' sense: max if they travel up the axis (+1), -min if down (-1)
     const float4* prims;
     const float4* triShade;
     const float4* spheres;
