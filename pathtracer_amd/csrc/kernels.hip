@@ -1318,10 +1318,10 @@ __global__ __launch_bounds__( kConnectBlock ) PT_CONNECT_OCCUPANCY void ConnectP
                 else
                     r = Load16( nodes, 16u * node );
                 const uint32_t x = __float_as_uint( r.x ), y = __float_as_uint( r.y ), word = __float_as_uint( r.w );
-                const bool inside = ( ( cell & 0xFFFFu ) - ( x & 0xFFFFu ) <= ( x >> 16 ) ) & ( ( cell >> 16 ) - ( y & 0xFFFFu ) <= ( y >> 16 ) ) & ( r.z > pw );
-                const bool isLeaf = ( word & kLeafFlag ) != 0;
-                node = ( isLeaf | inside ) ? second : word;
-                if ( isLeaf & inside ) leaf = word & ~kLeafFlag;
+                const bool inside = ( cell & 0xFFFFu ) - ( x & 0xFFFFu ) <= ( x >> 16 ) && ( cell >> 16 ) - ( y & 0xFFFFu ) <= ( y >> 16 ) && r.z > pw;
+                const bool isLeaf = static_cast< int32_t >( word ) < 0; // kLeafFlag
+                node = ( isLeaf || inside ) ? second : word;
+                if ( isLeaf && inside ) leaf = word & ~kLeafFlag;
             }
         }
     }
