@@ -265,11 +265,14 @@ def main():
             prof_s = profile.get("trace", {}).get("avg_ns", 0.0) * 1e-9 or launch_s
             busy = per.get("SQ_ACTIVE_INST_VALU", 0.0) * 4                    # SIMD cycles spent issuing vector instructions
             hbm.update({"fabric": round(traffic / prof_s / 1e9, 1), "fabric_frac": round(traffic / prof_s / 1e9 / HBM_PEAK_GBS, 4)})
-            # Three ceilings, each as busy cycles of the unit over the cycles it had: the SIMDs' vector issue (1,024
+            # The ceilings, each as busy cycles of the unit over the cycles it had: the SIMDs' vector issue (1,024
             # SIMDs; rocprofv3's VALUBusy), the texture addressers through which every vector memory instruction
-            # passes (one per CU; TA_TA_BUSY), and the memory system behind the L2 (bytes against the HBM peak).
+            # passes (one per CU; TA_TA_BUSY), the scalar units (one per CU), and the memory system behind the L2 (bytes
+            # against the HBM peak).
             ta_busy = per.get("TA_TA_BUSY_sum", 0.0)
             ceilings = {"valu_issue": (busy, 1024 * cycles), "texture_addresser": (ta_busy, 256 * cycles)}
+            if per.get("SQ_INSTS_SALU"):   # one scalar unit per CU, at most one instruction per cycle
+                ceilings["scalar_issue"] = (per["SQ_INSTS_SALU"], 256 * cycles)
             fracs = {k: round(a / b, 4) if b else 0.0 for k, (a, b) in ceilings.items()}
             fracs["hbm"] = hbm["fabric_frac"]
             bound = max(fracs, key=fracs.get)

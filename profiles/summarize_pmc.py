@@ -42,6 +42,9 @@ for k in sorted(tot):
         d["l2_hit_rate"] = 1 - per.get("TCC_MISS_sum", 0) / per["TCC_REQ_sum"]
     if "SQ_ACTIVE_INST_VALU" in per and per.get("GRBM_GUI_ACTIVE", 0) > 0:
         d["valu_utilization"] = per["SQ_ACTIVE_INST_VALU"] * 4 / (per["GRBM_GUI_ACTIVE"] / 8) / 1024
+    if "SQ_INSTS_SALU" in per and per.get("GRBM_GUI_ACTIVE", 0) > 0:
+        # one scalar unit per CU, one instruction per cycle at most
+        d["salu_utilization"] = per["SQ_INSTS_SALU"] / (per["GRBM_GUI_ACTIVE"] / 8) / 256
     if "TA_TA_BUSY_sum" in per and per.get("GRBM_GUI_ACTIVE", 0) > 0:
         d["ta_busy"] = per["TA_TA_BUSY_sum"] / 256 / (per["GRBM_GUI_ACTIVE"] / 8)   # mean over the 256 texture addressers
     if "SQ_WAVE_CYCLES" in per and per["SQ_WAVE_CYCLES"] > 0:
