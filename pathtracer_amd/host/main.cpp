@@ -321,7 +321,10 @@ int main( int argc, char** argv )
     // Perform all the renderings ("SamplesPerPixel": [ 8, 32, ... ]), src/main.cpp:30-49
     for ( size_t it = 0; it < sppList.size(); ++it )
     {
-        PathTracer pathTracer( gpuScenes, desc.image_width, desc.image_height, desc.camera, opt.hostTonemap, !opt.referenceOrder );
+        // front to back unless asked otherwise - or the tree is so small that the traversal kernels' LDS copy holds it
+        // whole, where that order only adds its third load per node step and its second pass (same picture either way)
+        const bool ordered = !opt.referenceOrder && desc.num_nodes > 2400;
+        PathTracer pathTracer( gpuScenes, desc.image_width, desc.image_height, desc.camera, opt.hostTonemap, ordered );
         PtStats stats{};
         const uint64_t seed = opt.haveSeed ? opt.seed : ( static_cast< uint64_t >( entropy() ) << 32 | entropy() );
         if ( !pathTracer.Render( sppList[it], seed, &stats ) )
