@@ -21,6 +21,9 @@
 // link, next to the index of its first child, and the traversal needs no stack: hit inner -> first child,
 // miss or leaf done -> link.  The visit sequence is exactly the reference's stack sequence, with no per-lane
 // stack in LDS or scratch, whatever order the nodes have in device memory.
+// Two more layouts serve the front-to-back mode (PT_RENDER_ORDERED): records with one link per octant of ray
+// directions for the closest hit (TraceClosestOrdered), and 16-byte records in the frame of a scene's one directional
+// light for its shadow rays (ConnectParallelKernel).  Both keep the reference's answers, not its counters.
 #include "pt_device.h"
 #include "pt_api.h"
 #include "pt_sincosf.h"
@@ -203,7 +206,7 @@ struct HitRecord
 };
 
 // One primitive test of a closest-hit leaf: Triangle::Intersect / Sphere::Intersect (src/shapes.cpp:117-123,
-// 52-61).  The record (48 bytes of a 64-byte slot) is fetched whole before its tag is looked at (one memory round trip); the
+// 52-61).  The record (the first 48 bytes of its 64-byte slot) is fetched whole before its tag is looked at (one memory round trip); the
 // triangle arithmetic runs on whatever was fetched and is discarded for a sphere record.
 // kOrdered (front-to-back traversal, see TraceClosestOrdered): the test accepts hits up to kBand times the closest
 // distance so far, and `ambiguous` records whether a second hit lies within that band of the closest one.
