@@ -364,6 +364,19 @@ int pt_clear_film( PtScene* scene );
 int pt_download_film( PtScene* scene, float* film_rgba );
 int pt_upload_film( PtScene* scene, const float* film_rgba );
 
+/* Replaces: BVH::Build with SplitMethod::SAH (src/bvh.cpp:204-228, the recursion of src/bvh.cpp:33-178 and the
+ * flattening of src/bvh.cpp:180-202), on GPU `device`.  `boxes` are n * 6 floats (min xyz, max xyz), one box per
+ * shape in scene order - what Shape::WorldSpaceAABB gives BVH::Build (src/bvh.cpp:209-215).  nodes_out receives the
+ * 2n - 1 nodes of the reference's pre-order array (every leaf holds one shape), order_out the n input indices in the
+ * order of BVH::shapes (order_out[k] = input index of the shape at position k; src/bvh.cpp:217-221), *num_nodes_out
+ * the node count, *device_ms_out the time the GPU spent building (without the copies); either of the last two may be
+ * null.  The tree equals the reference's node for node: same split axis, same bucket costs, same order of the shapes
+ * after every std::partition and std::nth_element (libstdc++ as in GCC 11) - a zero bound of a box may differ in its
+ * sign, which no consumer can tell.  Bounds must be finite.  The same interface as pth_build_bvh of pt_host.h, which
+ * is the host builder for the other split methods. */
+int pt_build_bvh( int32_t device, const float* boxes, uint64_t n, PtBvhNode* nodes_out, uint32_t* order_out,
+                  uint64_t* num_nodes_out, float* device_ms_out );
+
 /* Replaces: Scene::~Scene / BVH::~BVH (src/scene.cpp:13-19, src/bvh.cpp:7-13). */
 int pt_destroy_scene( PtScene* scene );
 

@@ -61,6 +61,13 @@ int pth_scene_info( PthScene* scene, PthSceneInfo* out );
 int pth_build_bvh( const float* boxes, uint64_t n, int32_t split_method, PtBvhNode* nodes_out,
                    uint32_t* order_out, uint64_t* num_nodes_out );
 
+/* Lets another builder make the trees of the scenes loaded or generated from now on whose split method is SAH:
+ * pt_build_bvh of pt_api.h has this signature and builds the same tree on GPU `device`.  A null builder restores the
+ * host builder.  A failing builder fails the scene (there is no silent second try).  Process-wide. */
+typedef int ( *PthBvhBuilder )( int32_t device, const float* boxes, uint64_t n, PtBvhNode* nodes_out, uint32_t* order_out,
+                                uint64_t* num_nodes_out, float* device_ms_out );
+int pth_set_bvh_builder( PthBvhBuilder builder, int32_t device );
+
 /* Camera::UpdateOrientationVectors (src/camera.cpp:6-14): rotation in radians -> view, up, right. */
 int pth_camera_vectors( const float rotation[3], float view[3], float up[3], float right[3] );
 

@@ -64,6 +64,8 @@ def lib():
         L.pt_upload_film.argtypes = [C.c_void_p, C.c_void_p]
         L.pt_merge_films.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_uint32]
         L.pt_destroy_scene.argtypes = [C.c_void_p]
+        L.pt_build_bvh.argtypes = [C.c_int32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64),
+                                   C.POINTER(C.c_float)]
         _LIB = L
     return _LIB
 
@@ -75,6 +77,21 @@ def _check(rc):
 
 def _f32(a):
     return np.ascontiguousarray(a, np.float32)
+
+
+def build_bvh(boxes, device=0, return_ms=False):
+    """BVH::Build with the SAH split (src/bvh.cpp:204-228) on the GPU.
+
+    boxes: (n, 6) float32 [min xyz, max xyz] -> (nodes record array of 2n - 1, order uint32 array of n); the same
+    result as pathtracer_amd.host.build_bvh, which runs on the CPU.  With return_ms also the build time on the GPU."""
+    boxes = np.ascontiguousarray(boxes, np.float32).reshape(-1, 6)
+    n = len(boxes)
+    nodes = np.zeros(max(2 * n - 1, 0), abi.NODE_DTYPE)
+    order = np.zeros(n, np.uint32)
+    count, ms = C.c_uint64(0), C.c_float(0)
+    _check(lib().pt_build_bvh(device, boxes.ctypes.data, n, nodes.ctypes.data, order.ctypes.data, C.byref(count), C.byref(ms)))
+    nodes = nodes[:count.value]
+    return (nodes, order, ms.value) if return_ms else (nodes, order)
 
 
 class DeviceScene:

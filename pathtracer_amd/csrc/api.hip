@@ -67,6 +67,21 @@ int Fail( int code, const char* fmt, ... )
     return code;
 }
 
+} // namespace
+
+namespace ptd
+{
+// for the other source files of the library: sets what pt_last_error returns on this thread
+int SetError( int code, const char* message )
+{
+    g_error = message;
+    return code;
+}
+} // namespace ptd
+
+namespace
+{
+
 // The C-ABI never lets an exception out (std::bad_alloc from the host-side staging vectors is the one that can
 // happen): every entry point is a function-try-block that ends here.
 int HostFailure( const char* where )

@@ -34,6 +34,7 @@ def lib():
         L.pth_scene_desc.argtypes = [C.c_void_p, C.c_int32, C.POINTER(abi.PtSceneDesc)]
         L.pth_scene_info.argtypes = [C.c_void_p, C.POINTER(abi.PthSceneInfo)]
         L.pth_build_bvh.argtypes = [C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]
+        L.pth_set_bvh_builder.argtypes = [C.c_void_p, C.c_int32]
         L.pth_camera_vectors.argtypes = [C.c_void_p] * 4
         L.pth_sphere_world_to_local.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
         L.pth_write_image.argtypes = [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32]
@@ -122,6 +123,16 @@ class HostScene:
 
     def to_data(self):
         return SceneData.from_desc(self.desc())
+
+
+def use_gpu_bvh_builder(device=0):
+    """Scenes loaded or generated from now on build their SAH trees with pt_build_bvh on GPU `device`
+    (None: back to the host builder).  The trees are the same node for node."""
+    if device is None:
+        _check(lib().pth_set_bvh_builder(None, 0))
+        return
+    from . import api
+    _check(lib().pth_set_bvh_builder(C.cast(api.lib().pt_build_bvh, C.c_void_p), device))
 
 
 def build_bvh(boxes, split_method=abi.PTH_SPLIT_SAH):

@@ -3,6 +3,7 @@
 #include <atomic>
 #include <cstdlib>
 #include <stdexcept>
+#include <string>
 #include <system_error>
 #include <thread>
 
@@ -230,6 +231,33 @@ BvhResult BuildBvh( const std::vector< Aabb >& bounds, SplitMethod method )
     if ( const char* env = std::getenv( "PT_BUILD_THREADS" ) ) threads = std::max( 1, std::atoi( env ) );
     Builder b{ items, method, out, { threads - 1 } };
     b.Emit( 0, static_cast< int >( bounds.size() ), 0 );
+    return out;
+}
+
+namespace
+{
+    std::atomic< ExternalBvhBuilder > g_externalBuilder{ nullptr };
+    std::atomic< int32_t > g_externalDevice{ 0 };
+} // namespace
+
+void SetExternalBvhBuilder( ExternalBvhBuilder builder, int32_t device )
+{
+    g_externalDevice  = device;
+    g_externalBuilder = builder;
+}
+
+BvhResult BuildSceneBvh( const std::vector< Aabb >& bounds, SplitMethod method )
+{
+    const ExternalBvhBuilder external = g_externalBuilder;
+    if ( !external || method != SplitMethod::SAH ) return BuildBvh( bounds, method );
+    if ( bounds.empty() ) throw std::runtime_error( "BuildBvh: scene has no shapes" );
+    static_assert( sizeof( Aabb ) == 24, "a box is six floats: min xyz, max xyz" );
+    BvhResult out;
+    out.nodes.resize( 2 * bounds.size() - 1 );
+    out.order.resize( bounds.size() );
+    uint64_t count = 0;
+    const int rc   = external( g_externalDevice, &bounds[0].min.x, bounds.size(), out.nodes.data(), out.order.data(), &count, nullptr );
+    if ( rc != 0 || count != out.nodes.size() ) throw std::runtime_error( "the external BVH builder failed (status " + std::to_string( rc ) + ")" );
     return out;
 }
 

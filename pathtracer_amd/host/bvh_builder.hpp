@@ -39,4 +39,12 @@ struct BvhResult
 // flattening.  Throws std::runtime_error if the recursion cannot make progress (all centroids equal).
 BvhResult BuildBvh( const std::vector< Aabb >& bounds, SplitMethod method );
 
+// A builder with the interface of pt_build_bvh (pt_api.h) that takes over the SAH trees of HostScene::BuildAccel,
+// or nullptr for BuildBvh above.
+using ExternalBvhBuilder = int ( * )( int32_t device, const float* boxes, uint64_t n, PtBvhNode* nodesOut, uint32_t* orderOut,
+                                      uint64_t* numNodesOut, float* deviceMsOut );
+void SetExternalBvhBuilder( ExternalBvhBuilder builder, int32_t device );
+// BuildBvh, or the external builder if one is set and the method is SAH; throws std::runtime_error if that one fails.
+BvhResult BuildSceneBvh( const std::vector< Aabb >& bounds, SplitMethod method );
+
 } // namespace pth

@@ -172,6 +172,12 @@ int pth_build_bvh( const float* boxes, uint64_t n, int32_t split_method, PtBvhNo
     } );
 }
 
+int pth_set_bvh_builder( PthBvhBuilder builder, int32_t device )
+{
+    pth::SetExternalBvhBuilder( builder, device );
+    return 0;
+}
+
 int pth_camera_vectors( const float rotation[3], float view[3], float up[3], float right[3] )
 {
     if ( !rotation || !view || !up || !right ) return Fail( "pth_camera_vectors: null argument" );

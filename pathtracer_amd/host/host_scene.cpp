@@ -203,7 +203,7 @@ void HostScene::BuildAccel()
         bounds[i] = b;
     }
 
-    BvhResult r = BuildBvh( bounds, splitMethod );
+    BvhResult r = BuildSceneBvh( bounds, splitMethod );
     nodes       = std::move( r.nodes );
     primToShape = std::move( r.order );
     prims.resize( primToShape.size() );

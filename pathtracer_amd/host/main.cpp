@@ -32,7 +32,7 @@ struct Options
     std::string sceneFile, resourceDir, output, generate;
     int width = 0, height = 0, depth = -1, spp = 0, device = 0, triangles = 0;
     uint64_t seed = 0;
-    bool haveSeed = false, stats = false, hostTonemap = false, referenceOrder = false;
+    bool haveSeed = false, stats = false, hostTonemap = false, referenceOrder = false, hostBvh = false;
     std::vector< int > devices; // --devices: the GPUs that share a render; empty = the one of --device
 };
 
@@ -56,6 +56,8 @@ void Help()
                  "  --stats              print ray and traversal counters after each render\n"
                  "  --reference-order    visit the BVH in the reference's first-child-first order instead of front to back:\n"
                  "                       same picture, traversal counters equal to the CPU path's, slower on large scenes\n"
+                 "  --host-bvh           build SAH trees on the host instead of the GPU (the same tree either way, node for\n"
+                 "                       node; the other split methods are always built on the host)\n"
                  "  --host-tonemap       run the tonemap pass on the host with the C library's powf, as the reference\n"
                  "                       does (the saved picture is then the CPU path's to the last bit for equal samples)\n";
 }
@@ -110,6 +112,8 @@ bool ParseArgs( int argc, char** argv, Options& o )
             o.hostTonemap = true;
         else if ( a == "--reference-order" )
             o.referenceOrder = true;
+        else if ( a == "--host-bvh" )
+            o.hostBvh = true;
         else if ( a == "--seed" && ( v = value() ) )
         {
             o.seed     = std::strtoull( v, nullptr, 0 );
@@ -253,6 +257,8 @@ int main( int argc, char** argv )
     int rc;
     const auto loadStart = std::chrono::steady_clock::now();
     std::cout << "Loading scene '" << ( opt.generate.empty() ? opt.sceneFile : opt.generate ) << "'..." << std::endl;
+    // BVH::Build with the SAH split runs on the GPU that renders (pt_build_bvh: the reference's tree, node for node)
+    if ( !opt.hostBvh ) pth_set_bvh_builder( pt_build_bvh, opt.devices.empty() ? opt.device : opt.devices[0] );
     if ( opt.generate.empty() )
     {
         const std::string resourceDir = opt.resourceDir.empty() ? DefaultResourceDir( opt.sceneFile ) : opt.resourceDir;
@@ -272,7 +278,9 @@ int main( int argc, char** argv )
     if ( rc != 0 )
     {
         // the reference logs the failure and exits with status 0 (src/main.cpp:25-29)
-        std::cout << "Could not load scene file '" << ( opt.generate.empty() ? opt.sceneFile : opt.generate ) << "': " << pth_last_error() << std::endl;
+        std::cout << "Could not load scene file '" << ( opt.generate.empty() ? opt.sceneFile : opt.generate ) << "': " << pth_last_error();
+        if ( *pt_last_error() ) std::cout << " (" << pt_last_error() << ")"; // the GPU tree builder's own words, if it was the one that failed
+        std::cout << std::endl;
         return 0;
     }
     if ( opt.width > 0 && opt.height > 0 ) pth_set_image( scene, opt.width, opt.height, static_cast< float >( opt.width ) / opt.height );

@@ -1,0 +1,132 @@
+"""The GPU builder of the reference's SAH tree (pt_build_bvh) against the host builder (pth_build_bvh), which
+tests/test_oracle_vs_reference.py pins node for node against the reference's own BVH::Build.
+
+Bar: the shape order, every node's offset / shape count / axis bit-equal; the boxes equal as floats (a zero bound may
+differ in its sign: the reference keeps the sign of the first zero it meets, a parallel minimum cannot).
+"""
+import numpy as np
+import pytest
+
+from pathtracer_amd import abi, api, host
+
+pytestmark = pytest.mark.gpu
+
+
+def boxes_from_points(lo, extent):
+    lo = np.asarray(lo, np.float32)
+    return np.concatenate([lo, (lo + np.asarray(extent, np.float32)).astype(np.float32)], axis=1)
+
+
+def assert_same_tree(boxes, what):
+    want_nodes, want_order = host.build_bvh(boxes, abi.PTH_SPLIT_SAH)
+    nodes, order = api.build_bvh(boxes)
+    assert len(nodes) == len(want_nodes) == 2 * len(boxes) - 1, what
+    wrong = np.flatnonzero(order != want_order)
+    assert wrong.size == 0, f"{what}: shape order differs first at position {wrong[0]} of {len(order)} ({wrong.size} in all)"
+    for field in ("offset", "num_shapes", "axis"):
+        wrong = np.flatnonzero(nodes[field] != want_nodes[field])
+        assert wrong.size == 0, f"{what}: node {wrong[0]} differs in {field}: {nodes[field][wrong[0]]} != {want_nodes[field][wrong[0]]}"
+    for field in ("aabb_min", "aabb_max"):
+        wrong = np.flatnonzero((nodes[field] != want_nodes[field]).any(axis=1))
+        assert wrong.size == 0, f"{what}: node {wrong[0]} differs in {field}: {nodes[field][wrong[0]]} != {want_nodes[field][wrong[0]]}"
+    return nodes, order
+
+
+@pytest.mark.parametrize("n", list(range(1, 41)) + [63, 64, 65, 100, 257, 1000, 1023, 1024, 1025, 4097])
+def test_small_counts(n):
+    rng = np.random.default_rng(n)
+    boxes = boxes_from_points(rng.uniform(-1, 1, (n, 3)), rng.uniform(0, 0.2, (n, 3)))
+    assert_same_tree(boxes, f"{n} random boxes")
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_ties_and_degenerate_ranges(seed):
+    """Centroids on a coarse grid (equal keys for nth_element and whole ranges in one bucket), boxes without extent,
+    shapes that coincide: the ranges std::partition leaves untouched and the ones that are halved where they lie."""
+    rng = np.random.default_rng(100 + seed)
+    n = [7, 50, 300, 2000, 5000, 20000][seed]
+    grid = [1, 2, 3, 4, 8, 2][seed]
+    lo = rng.integers(0, grid, (n, 3)).astype(np.float32)
+    extent = rng.integers(0, 2, (n, 3)).astype(np.float32) * np.float32(0.5)
+    if seed % 2:
+        extent[:] = 0
+    assert_same_tree(boxes_from_points(lo, extent), f"grid {grid}, {n} boxes")
+
+
+def test_all_shapes_coincide():
+    boxes = np.tile(np.array([[1, 2, 3, 1.5, 2.5, 3.5]], np.float32), (1000, 1))
+    nodes, order = assert_same_tree(boxes, "1000 equal boxes")
+    assert (np.sort(order) == np.arange(1000)).all()
+
+
+def test_signed_zero_bounds():
+    rng = np.random.default_rng(5)
+    n = 5000
+    boxes = boxes_from_points(rng.uniform(-1, 1, (n, 3)), rng.uniform(0, 0.2, (n, 3)))
+    boxes[rng.integers(0, n, 500), rng.integers(0, 3, 500)] = np.float32(-0.0)
+    boxes[rng.integers(0, n, 500), 3 + rng.integers(0, 3, 500)] = np.float32(0.0)
+    boxes[:, :3] = np.minimum(boxes[:, :3], boxes[:, 3:])
+    assert_same_tree(boxes, "zeros of both signs")
+
+
+def test_flat_and_far_geometry():
+    """All shapes in one plane (a box without volume: the costs divide by a zero area), and a cloud far from the
+    origin, where centroids collapse onto few floats."""
+    rng = np.random.default_rng(8)
+    n = 3000
+    lo = rng.uniform(-1, 1, (n, 3))
+    lo[:, 1] = 0.25
+    extent = rng.uniform(0, 0.1, (n, 3))
+    extent[:, 1] = 0
+    assert_same_tree(boxes_from_points(lo, extent), "flat")
+    far = boxes_from_points(rng.uniform(-1, 1, (n, 3)) + 1.0e6, rng.uniform(0, 0.2, (n, 3)))
+    assert_same_tree(far, "far from the origin")
+
+
+def leaf_boxes(hs):
+    nodes = hs.to_data().nodes
+    leaves = nodes[nodes["num_shapes"] > 0]
+    return np.concatenate([leaves["aabb_min"], leaves["aabb_max"]], axis=1).astype(np.float32)
+
+
+def test_small_atrium():
+    hs = host.HostScene.atrium(seed=4, triangles=3000, texture_size=16)
+    try:
+        boxes = leaf_boxes(hs)
+    finally:
+        hs.close()
+    rng = np.random.default_rng(0)
+    assert_same_tree(boxes[rng.permutation(len(boxes))], "small atrium")
+
+
+def test_benchmark_scenes():
+    """The triangles of the benchmark's atrium and of the knot, in a shuffled order."""
+    for make, what in ((lambda: host.HostScene.atrium(seed=1, triangles=262267, texture_size=16), "atrium"),
+                       (lambda: host.HostScene.knot(seed=2, triangles=871414), "knot")):
+        hs = make()
+        try:
+            boxes = leaf_boxes(hs)
+        finally:
+            hs.close()
+        rng = np.random.default_rng(1)
+        nodes, order, ms = api.build_bvh(boxes[rng.permutation(len(boxes))], return_ms=True)
+        print(f"{what}: {len(boxes)} shapes, {ms:.1f} ms on the GPU")
+        assert_same_tree(boxes[rng.permutation(len(boxes))], what)
+
+
+def test_two_million_triangle_soup():
+    rng = np.random.default_rng(3)
+    n = 2_000_000
+    centre = rng.uniform(-1, 1, (n, 3)).astype(np.float32)
+    half = rng.uniform(0, 0.01, (n, 3)).astype(np.float32)
+    boxes = np.concatenate([centre - half, centre + half], axis=1).astype(np.float32)
+    assert_same_tree(boxes, "soup of 2 M boxes")
+
+
+def test_rejects_what_it_cannot_build():
+    with pytest.raises(api.PtError):
+        api.build_bvh(np.zeros((0, 6), np.float32))
+    bad = np.zeros((10, 6), np.float32)
+    bad[3, 4] = np.inf
+    with pytest.raises(api.PtError):
+        api.build_bvh(bad)

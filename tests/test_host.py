@@ -195,12 +195,20 @@ def test_command_line_host_usage_and_failures(tmp_path):
     assert r.returncode == 0 and r.stdout.strip() == "Usage: pathTracer SCENE_FILE"
     r = subprocess.run([exe, str(tmp_path / "missing.json")], capture_output=True, text=True)
     assert r.returncode == 0 and "Could not load scene file" in r.stdout
-    r = subprocess.run([exe, "--generate", "knot", "--triangles", "2000", "--width", "32", "--height", "32", "--spp", "1",
-                        "--output", str(tmp_path / "k.png")], capture_output=True, text=True, cwd=tmp_path)
-    assert r.returncode == 0 and "Number of shapes: 2000" in r.stdout and "\tTriangles: 2000" in r.stdout
     import torch
+    knot = [exe, "--generate", "knot", "--triangles", "2000", "--width", "32", "--height", "32", "--spp", "1",
+            "--output", str(tmp_path / "k.png")]
+    r = subprocess.run(knot + ["--host-bvh"], capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode == 0 and "Number of shapes: 2000" in r.stdout and "\tTriangles: 2000" in r.stdout
     if not torch.cuda.is_available():
         assert "Could not upload the scene" in r.stdout and not (tmp_path / "k.png").exists()
+    # the tree of a SAH scene is built on the GPU unless --host-bvh says otherwise: no GPU, no scene
+    r = subprocess.run(knot, capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode == 0
+    if not torch.cuda.is_available():
+        assert "Could not load scene file" in r.stdout and "pt_build_bvh" in r.stdout and not (tmp_path / "k.png").exists()
+    else:
+        assert "Number of shapes: 2000" in r.stdout
 
 
 def test_picture_files_decode_and_save_like_the_committed_reference_vectors(tmp_path):
