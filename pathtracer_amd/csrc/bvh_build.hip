@@ -13,8 +13,9 @@
 //   * std::partition over a range is a fixed permutation: the k-th element from the left that fails the predicate and
 //     lies before the partition point changes places with the k-th element from the right that passes it and lies
 //     behind - positions a prefix sum of the predicate gives to every element at once;
-//   * ranges of at most four shapes are finished by one thread each with the element moves of libstdc++'s
-//     std::nth_element (GCC 11: one median-of-three partition step for four elements, then insertion sort).
+//   * ranges of at most 32 shapes are finished by one thread each, which walks the reference's recursion itself, with
+//     the element moves of libstdc++'s std::partition and std::nth_element (GCC 11; on at most four elements: one
+//     median-of-three partition step for four, then insertion sort).
 // All arithmetic is float32 in the reference's operation order, compiled without contraction.
 #include "pt_api.h"
 
@@ -35,6 +36,7 @@ namespace
 constexpr uint32_t kNone       = 0xFFFFFFFFu;
 constexpr int kBuckets         = 12; // src/bvh.cpp:102
 constexpr uint32_t kSmallRange = 4;  // src/bvh.cpp:95,150
+constexpr uint32_t kThreadRange = 32; // a range of at most this many shapes is finished by one thread
 constexpr int kBlock           = 1024;
 constexpr int kWaves           = kBlock / 64;
 constexpr int kMaxRuns         = 32; // ranges a block may meet and still combine their sums in LDS
@@ -102,7 +104,7 @@ __device__ __forceinline__ int BucketOf( float centroid, float cMin, float cMax 
 // where it is needed.
 __device__ __forceinline__ float Centroid( float lo, float hi ) { return 0.5f * ( lo + hi ); }
 
-// A range of more than four shapes that this level splits.
+// A range of more than kThreadRange shapes that this level splits.
 struct BigRange
 {
     uint32_t start, end, slot, cutoff;
@@ -111,7 +113,7 @@ struct BigRange
     uint32_t acc[12]; // Enc of: box lo xyz, centroid box lo xyz (minima), box hi xyz, centroid box hi xyz (maxima)
     float cMin, cMax; // centroid box along dim
     float area;       // SurfaceArea of the range's box
-    uint32_t pad;
+    uint32_t needReduce; // box and centroid box still have to be summed from the shapes
 };
 static_assert( sizeof( BigRange ) == 96, "BigRange is 24 words" );
 
@@ -120,10 +122,12 @@ struct SmallRange
     uint32_t start, end, slot;
 };
 
-// bucket sums of one range: [bucket][0] = count, [1..3] = Enc( lo ), [4..6] = Enc( hi )
+// bucket sums of one range: [bucket][0] = count, [1..3] = Enc( box lo ), [4..6] = Enc( centroid box lo ) (minima),
+// [7..9] = Enc( box hi ), [10..12] = Enc( centroid box hi ) (maxima)
+constexpr uint32_t kBucketWords = 16;
 struct Buckets
 {
-    uint32_t w[kBuckets][8];
+    uint32_t w[kBuckets][kBucketWords];
 };
 
 __device__ __forceinline__ void WriteNode( uint32_t* nodes, uint32_t slot, const Box& box, uint32_t offset, uint32_t numShapes, uint32_t axis )
@@ -159,25 +163,15 @@ __device__ __forceinline__ uint32_t RunIndex( uint32_t r, uint32_t* sLast, uint3
     return base + upTo - 1u;
 }
 
-// Level step 1: every shape finds the range it belongs to now (its old range's left or right half) and adds its
-// box and centroid to that range's sums.
-__global__ __launch_bounds__( kBlock ) void ReduceKernel( const float4* __restrict__ items, uint32_t* __restrict__ seg, const BigRange* __restrict__ prev,
-                                                           BigRange* __restrict__ cur, uint32_t n, int level )
+// Only for ranges whose box the level before could not hand down (the root; the halves of a range that was halved
+// where it lay): every shape of such a range adds its box and centroid to the range's sums.
+__global__ __launch_bounds__( kBlock ) void ReduceKernel( const float4* __restrict__ items, const uint32_t* __restrict__ seg, BigRange* __restrict__ cur, uint32_t n )
 {
     __shared__ uint32_t sLast[kWaves], sHeads[kWaves];
     __shared__ uint32_t sAcc[kMaxRuns][12];
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    uint32_t r       = kNone;
-    if ( i < n )
-    {
-        r = seg[i];
-        if ( level > 0 && r != kNone )
-        {
-            const BigRange* p = prev + r;
-            r                 = i < p->cutoff ? p->left : p->right;
-            seg[i]            = r;
-        }
-    }
+    uint32_t r       = i < n ? seg[i] : kNone;
+    if ( r != kNone && !cur[r].needReduce ) r = kNone;
     uint32_t v[12];
     if ( r != kNone )
     {
@@ -215,11 +209,23 @@ __global__ __launch_bounds__( kBlock ) void ReduceKernel( const float4* __restri
     }
 }
 
-// Level step 2: box, split axis and node record of every range; its bucket sums start empty.
-__global__ void AxisKernel( BigRange* __restrict__ cur, Buckets* __restrict__ buckets, uint32_t count, uint32_t* __restrict__ nodes )
+// What a range needs before its shapes can be sorted into buckets: split axis (src/bvh.cpp:68-70), the centroid
+// bounds along it, the area of its box - and its node record, which gets the second child's slot in SplitKernel.
+__device__ __forceinline__ void PrepareRange( BigRange& R, const Box& box, const Box& cbox, uint32_t* nodes )
+{
+    const int dim = LongestDimension( cbox );
+    R.dim         = static_cast< uint32_t >( dim );
+    R.cMin        = cbox.lo[dim];
+    R.cMax        = cbox.hi[dim];
+    R.area        = SurfaceArea( box );
+    WriteNode( nodes, R.slot, box, 0u, 0u, static_cast< uint32_t >( dim ) );
+}
+
+// The ranges ReduceKernel summed: box and centroid box from the sums.
+__global__ void AxisKernel( BigRange* __restrict__ cur, uint32_t count, uint32_t* __restrict__ nodes )
 {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if ( r >= count ) return;
+    if ( r >= count || !cur[r].needReduce ) return;
     BigRange& R = cur[r];
     Box box, cbox;
     for ( int k = 0; k < 3; ++k )
@@ -229,90 +235,224 @@ __global__ void AxisKernel( BigRange* __restrict__ cur, Buckets* __restrict__ bu
         box.hi[k]  = Dec( R.acc[6 + k] );
         cbox.hi[k] = Dec( R.acc[9 + k] );
     }
-    const int dim = LongestDimension( cbox ); // src/bvh.cpp:68-70
-    R.dim         = static_cast< uint32_t >( dim );
-    R.cMin        = cbox.lo[dim];
-    R.cMax        = cbox.hi[dim];
-    R.area        = SurfaceArea( box );
-    WriteNode( nodes, R.slot, box, 0u, 0u, static_cast< uint32_t >( dim ) ); // the second child's slot follows in SplitKernel
-    for ( int b = 0; b < kBuckets; ++b )
-    {
-        uint4* w = reinterpret_cast< uint4* >( buckets[r].w[b] );
-        w[0]     = uint4{ 0u, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu };
-        w[1]     = uint4{ 0u, 0u, 0u, 0u };
-    }
+    PrepareRange( R, box, cbox, nodes );
 }
 
-// Level step 3: bucket counts and bucket boxes (src/bvh.cpp:104-112).
-__global__ __launch_bounds__( kBlock ) void BucketKernel( const float4* __restrict__ items, const uint32_t* __restrict__ seg, const BigRange* __restrict__ cur,
-                                                           Buckets* __restrict__ buckets, uint32_t n )
+// Every shape finds the range it belongs to now: its old range's first or second half.
+__global__ __launch_bounds__( kBlock ) void SegUpdateKernel( uint32_t* __restrict__ seg, const BigRange* __restrict__ prev, uint32_t n )
 {
-    __shared__ uint32_t sLast[kWaves], sHeads[kWaves];
-    __shared__ uint32_t sBk[kMaxRuns][kBuckets][7];
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    const uint32_t r = i < n ? seg[i] : kNone;
-    uint32_t v[6];
-    int b = 0;
-    if ( r != kNone )
+    if ( i >= n ) return;
+    const uint32_t r = seg[i];
+    if ( r == kNone ) return;
+    const BigRange* p = prev + r;
+    seg[i]            = i < p->cutoff ? p->left : p->right;
+}
+
+__global__ void InitBucketsKernel( uint32_t* __restrict__ words, uint32_t count )
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if ( k >= count ) return;
+    const uint32_t word = k % kBucketWords;
+    words[k]            = ( word >= 1 && word <= 6 ) ? 0xFFFFFFFFu : 0u; // count 0, minima at the top, maxima at the bottom
+}
+
+// Level step 1 (src/bvh.cpp:104-112, and for the level after: src/bvh.cpp:41-45,62-70): every shape moves on to its
+// half of its old range (updateSeg), finds its bucket along its range's split axis and adds itself to the bucket's
+// count, box and centroid box.  The unions of the buckets on either side of the split that SplitKernel picks are
+// the boxes and centroid boxes of the two halves: the next level starts with them and sums nothing else.
+//
+// A block takes `tiles` consecutive tiles of kBlock shapes.  Ranges are intervals of positions, so if the first and
+// the last shape of the block's tiles are in the same range, all of them are: then every wave sums into its own
+// copy of the twelve buckets in LDS and the block adds the copies to the range's sums once.  Otherwise each tile is
+// cut into its runs of equal range, at most kMaxRuns of them summed in LDS, more than that straight in memory.
+__global__ __launch_bounds__( kBlock ) void BucketKernel( const float4* __restrict__ items, uint32_t* __restrict__ seg, const BigRange* __restrict__ prev,
+                                                           const BigRange* __restrict__ cur, Buckets* __restrict__ buckets, uint32_t n, uint32_t tiles,
+                                                           int updateSeg )
+{
+    __shared__ uint32_t sLast[kWaves], sHeads[kWaves], sRunRange[kMaxRuns], sEnds[2];
+    __shared__ uint32_t sBk[kMaxRuns * kBuckets * kBucketWords]; // [run or wave][bucket][word]
+    const uint32_t first = blockIdx.x * tiles * kBlock;
+    const uint32_t wave  = threadIdx.x >> 6;
+    auto rangeOf = [&]( uint32_t i ) -> uint32_t {
+        uint32_t r = seg[i];
+        if ( updateSeg && r != kNone )
+        {
+            const BigRange* p = prev + r;
+            r                 = i < p->cutoff ? p->left : p->right;
+        }
+        return r;
+    };
+    if ( threadIdx.x < 2 )
     {
-        const float4 lo = items[2ull * i], hi = items[2ull * i + 1];
-        const BigRange* R = cur + r;
-        const uint32_t dim = R->dim;
-        const float c = dim == 0 ? Centroid( lo.x, hi.x ) : dim == 1 ? Centroid( lo.y, hi.y ) : Centroid( lo.z, hi.z );
-        b    = BucketOf( c, R->cMin, R->cMax );
-        v[0] = Enc( lo.x ); v[1] = Enc( lo.y ); v[2] = Enc( lo.z );
-        v[3] = Enc( hi.x ); v[4] = Enc( hi.y ); v[5] = Enc( hi.z );
+        const uint32_t lastInBlock = first + tiles * kBlock - 1u;
+        sEnds[threadIdx.x]         = rangeOf( threadIdx.x == 0 ? first : ( lastInBlock < n ? lastInBlock : n - 1u ) );
     }
-    uint32_t runs;
-    bool head;
-    const uint32_t run = RunIndex( r, sLast, sHeads, &runs, &head );
-    if ( runs <= kMaxRuns )
+    __syncthreads();
+    const uint32_t only = sEnds[0];
+    const bool oneRange = only == sEnds[1] && only != kNone;
+    if ( oneRange )
     {
-        for ( uint32_t k = threadIdx.x; k < runs * kBuckets * 7; k += kBlock )
+        for ( uint32_t k = threadIdx.x; k < kWaves * kBuckets * kBucketWords; k += kBlock )
         {
-            const uint32_t word = k % 7u;
-            ( &sBk[0][0][0] )[k] = word == 0 ? 0u : word < 4 ? 0xFFFFFFFFu : 0u;
+            const uint32_t word = k % kBucketWords;
+            sBk[k]              = ( word >= 1 && word <= 6 ) ? 0xFFFFFFFFu : 0u;
         }
         __syncthreads();
-        if ( r != kNone )
+        const BigRange* R  = cur + only;
+        const uint32_t dim = R->dim & 0xFFu;
+        const float cMin = R->cMin, cMax = R->cMax;
+        for ( uint32_t t = 0; t < tiles; ++t )
         {
-            atomicAdd( &sBk[run][b][0], 1u );
-            for ( int k = 0; k < 3; ++k ) atomicMin( &sBk[run][b][1 + k], v[k] );
-            for ( int k = 3; k < 6; ++k ) atomicMax( &sBk[run][b][1 + k], v[k] );
+            const uint32_t i = first + t * kBlock + threadIdx.x;
+            if ( i >= n ) break;
+            if ( updateSeg ) seg[i] = only;
+            const float4 lo = items[2ull * i], hi = items[2ull * i + 1];
+            const float cx = Centroid( lo.x, hi.x ), cy = Centroid( lo.y, hi.y ), cz = Centroid( lo.z, hi.z );
+            const int b    = BucketOf( dim == 0 ? cx : dim == 1 ? cy : cz, cMin, cMax );
+            uint32_t* w    = sBk + ( wave * kBuckets + b ) * kBucketWords;
+            atomicAdd( w, 1u );
+            atomicMin( w + 1, Enc( lo.x ) ); atomicMin( w + 2, Enc( lo.y ) ); atomicMin( w + 3, Enc( lo.z ) );
+            atomicMin( w + 4, Enc( cx ) );   atomicMin( w + 5, Enc( cy ) );   atomicMin( w + 6, Enc( cz ) );
+            atomicMax( w + 7, Enc( hi.x ) ); atomicMax( w + 8, Enc( hi.y ) ); atomicMax( w + 9, Enc( hi.z ) );
+            atomicMax( w + 10, Enc( cx ) );  atomicMax( w + 11, Enc( cy ) );  atomicMax( w + 12, Enc( cz ) );
         }
         __syncthreads();
-        if ( head && r != kNone )
+        if ( threadIdx.x < kBuckets * kBucketWords )
         {
-            for ( int q = 0; q < kBuckets; ++q )
+            const uint32_t b = threadIdx.x / kBucketWords, word = threadIdx.x % kBucketWords;
+            uint32_t total = 0;
+            for ( uint32_t w = 0; w < kWaves; ++w ) total += sBk[( w * kBuckets + b ) * kBucketWords];
+            if ( total && word < 13 )
             {
-                const uint32_t cnt = sBk[run][q][0];
-                if ( cnt == 0 ) continue;
-                uint32_t* g = buckets[r].w[q];
-                atomicAdd( g, cnt );
-                for ( int k = 0; k < 3; ++k ) atomicMin( g + 1 + k, sBk[run][q][1 + k] );
-                for ( int k = 3; k < 6; ++k ) atomicMax( g + 1 + k, sBk[run][q][1 + k] );
+                uint32_t value = word == 0 ? 0u : word <= 6 ? 0xFFFFFFFFu : 0u;
+                for ( uint32_t w = 0; w < kWaves; ++w )
+                {
+                    const uint32_t x = sBk[( w * kBuckets + b ) * kBucketWords + word];
+                    value            = word == 0 ? value + x : word <= 6 ? ( x < value ? x : value ) : ( x > value ? x : value );
+                }
+                uint32_t* g = buckets[only].w[b] + word;
+                if ( word == 0 ) atomicAdd( g, value );
+                else if ( word <= 6 ) atomicMin( g, value );
+                else atomicMax( g, value );
             }
         }
+        return;
     }
-    else if ( r != kNone )
+    for ( uint32_t t = 0; t < tiles; ++t )
     {
-        uint32_t* g = buckets[r].w[b];
-        atomicAdd( g, 1u );
-        for ( int k = 0; k < 3; ++k ) atomicMin( g + 1 + k, v[k] );
-        for ( int k = 3; k < 6; ++k ) atomicMax( g + 1 + k, v[k] );
+        const uint32_t i = first + t * kBlock + threadIdx.x;
+        if ( first + t * kBlock >= n ) break; // the whole tile lies behind the last shape
+        const uint32_t r = i < n ? rangeOf( i ) : kNone;
+        if ( updateSeg && i < n ) seg[i] = r;
+        uint32_t v[12];
+        int b = 0;
+        if ( r != kNone )
+        {
+            const float4 lo = items[2ull * i], hi = items[2ull * i + 1];
+            const BigRange* R = cur + r;
+            const uint32_t dim = R->dim & 0xFFu;
+            const float cx = Centroid( lo.x, hi.x ), cy = Centroid( lo.y, hi.y ), cz = Centroid( lo.z, hi.z );
+            b    = BucketOf( dim == 0 ? cx : dim == 1 ? cy : cz, R->cMin, R->cMax );
+            v[0] = Enc( lo.x ); v[1] = Enc( lo.y ); v[2] = Enc( lo.z ); v[3] = Enc( cx ); v[4] = Enc( cy ); v[5] = Enc( cz );
+            v[6] = Enc( hi.x ); v[7] = Enc( hi.y ); v[8] = Enc( hi.z ); v[9] = v[3]; v[10] = v[4]; v[11] = v[5];
+        }
+        uint32_t runs;
+        bool head;
+        const uint32_t run = RunIndex( r, sLast, sHeads, &runs, &head );
+        if ( runs <= kMaxRuns )
+        {
+            for ( uint32_t k = threadIdx.x; k < runs * kBuckets * kBucketWords; k += kBlock )
+            {
+                const uint32_t word = k % kBucketWords;
+                sBk[k]              = ( word >= 1 && word <= 6 ) ? 0xFFFFFFFFu : 0u;
+            }
+            if ( head ) sRunRange[run] = r;
+            __syncthreads();
+            if ( r != kNone )
+            {
+                uint32_t* w = sBk + ( run * kBuckets + b ) * kBucketWords;
+                atomicAdd( w, 1u );
+                for ( int k = 0; k < 6; ++k ) atomicMin( w + 1 + k, v[k] );
+                for ( int k = 6; k < 12; ++k ) atomicMax( w + 1 + k, v[k] );
+            }
+            __syncthreads();
+            for ( uint32_t k = threadIdx.x; k < runs * kBuckets * kBucketWords; k += kBlock )
+            {
+                const uint32_t word = k % kBucketWords, q = k / kBucketWords % kBuckets, owner = sRunRange[k / ( kBuckets * kBucketWords )];
+                if ( owner == kNone || word >= 13 || sBk[k - word] == 0 ) continue;
+                uint32_t* g = buckets[owner].w[q] + word;
+                if ( word == 0 ) atomicAdd( g, sBk[k] );
+                else if ( word <= 6 ) atomicMin( g, sBk[k] );
+                else atomicMax( g, sBk[k] );
+            }
+            __syncthreads(); // the next tile clears what this one still reads
+        }
+        else if ( r != kNone )
+        {
+            uint32_t* g = buckets[r].w[b];
+            atomicAdd( g, 1u );
+            for ( int k = 0; k < 6; ++k ) atomicMin( g + 1 + k, v[k] );
+            for ( int k = 6; k < 12; ++k ) atomicMax( g + 1 + k, v[k] );
+        }
     }
 }
 
-__device__ __forceinline__ void NewRange( uint32_t start, uint32_t end, uint32_t slot, BigRange* next, uint32_t* counters, SmallRange* small, uint32_t* id )
+// The cheapest of the eleven splits between the twelve buckets (src/bvh.cpp:114-147).  The union of buckets 0..i is
+// built up as i grows, which is the reference's own order of operations; the union of buckets i+1..11 from the far
+// end, which gives the same bounds.
+__device__ __forceinline__ int CheapestSplit( const Box* bb, const int* cnt, float area )
 {
-    if ( end - start > kSmallRange )
+    float areaBehind[kBuckets - 1];
+    int countBehind[kBuckets - 1];
+    Box b1 = EmptyBox();
+    int count1 = 0;
+    for ( int i = kBuckets - 2; i >= 0; --i )
+    {
+        Union( b1, bb[i + 1] );
+        count1 += cnt[i + 1];
+        areaBehind[i]  = SurfaceArea( b1 );
+        countBehind[i] = count1;
+    }
+    float minCost = 0;
+    int minBucket = 0, count0 = 0;
+    Box b0 = EmptyBox();
+    for ( int i = 0; i < kBuckets - 1; ++i )
+    {
+        Union( b0, bb[i] );
+        count0 += cnt[i];
+        const float cost = 0.5f + ( count0 * SurfaceArea( b0 ) + countBehind[i] * areaBehind[i] ) / area;
+        if ( i == 0 || cost < minCost )
+        {
+            minCost   = cost;
+            minBucket = i;
+        }
+    }
+    return minBucket;
+}
+
+__device__ __forceinline__ Box ItemBox( const float4* items, uint32_t i )
+{
+    const float4 lo = items[2ull * i], hi = items[2ull * i + 1];
+    return Box{ { lo.x, lo.y, lo.z }, { hi.x, hi.y, hi.z } };
+}
+
+// A half of a split range becomes a range of the next level (with its box and centroid box, if the split knows
+// them) or, if it is small, the work of one thread.
+__device__ __forceinline__ void NewRange( uint32_t start, uint32_t end, uint32_t slot, bool known, const Box& box, const Box& cbox, uint32_t* nodes,
+                                          BigRange* next, uint32_t* counters, SmallRange* small, uint32_t* id )
+{
+    if ( end - start > kThreadRange )
     {
         const uint32_t k = atomicAdd( counters + 0, 1u );
         BigRange& R      = next[k];
         R.start = start; R.end = end; R.slot = slot; R.cutoff = start;
         R.left = R.right = kNone;
         R.dim = 0; R.noMove = 0;
+        R.needReduce = known ? 0u : 1u;
         for ( int q = 0; q < 12; ++q ) R.acc[q] = q < 6 ? 0xFFFFFFFFu : 0u;
+        if ( known ) PrepareRange( R, box, cbox, nodes );
+        else atomicAdd( counters + 2, 1u );
         *id = k;
     }
     else
@@ -323,7 +463,7 @@ __device__ __forceinline__ void NewRange( uint32_t start, uint32_t end, uint32_t
     }
 }
 
-// Level step 4: the eleven split costs, the cheapest split, the partition point and the two ranges of the next
+// Level step 2: the eleven split costs, the cheapest split, the partition point and the two ranges of the next
 // level (src/bvh.cpp:114-169).
 __global__ void SplitKernel( BigRange* __restrict__ cur, const Buckets* __restrict__ buckets, uint32_t count, uint32_t* __restrict__ nodes, BigRange* __restrict__ next,
                              SmallRange* __restrict__ small, uint32_t* __restrict__ counters )
@@ -331,7 +471,7 @@ __global__ void SplitKernel( BigRange* __restrict__ cur, const Buckets* __restri
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if ( r >= count ) return;
     BigRange& R = cur[r];
-    Box bb[kBuckets];
+    Box bb[kBuckets], cb[kBuckets];
     int cnt[kBuckets];
     for ( int b = 0; b < kBuckets; ++b )
     {
@@ -341,48 +481,36 @@ __global__ void SplitKernel( BigRange* __restrict__ cur, const Buckets* __restri
         for ( int k = 0; k < 3; ++k )
         {
             bb[b].lo[k] = cnt[b] ? Dec( w[1 + k] ) : kFltMax;
-            bb[b].hi[k] = cnt[b] ? Dec( w[4 + k] ) : -kFltMax;
+            cb[b].lo[k] = cnt[b] ? Dec( w[4 + k] ) : kFltMax;
+            bb[b].hi[k] = cnt[b] ? Dec( w[7 + k] ) : -kFltMax;
+            cb[b].hi[k] = cnt[b] ? Dec( w[10 + k] ) : -kFltMax;
         }
     }
-    float minCost = 0;
-    int minBucket = 0;
-    for ( int i = 0; i < kBuckets - 1; ++i )
-    {
-        Box b0 = EmptyBox(), b1 = EmptyBox();
-        int count0 = 0, count1 = 0;
-        for ( int j = 0; j <= i; ++j )
-        {
-            Union( b0, bb[j] );
-            count0 += cnt[j];
-        }
-        for ( int j = i + 1; j < kBuckets; ++j )
-        {
-            Union( b1, bb[j] );
-            count1 += cnt[j];
-        }
-        const float cost = 0.5f + ( count0 * SurfaceArea( b0 ) + count1 * SurfaceArea( b1 ) ) / R.area;
-        if ( i == 0 || cost < minCost )
-        {
-            minCost   = cost;
-            minBucket = i;
-        }
-    }
+    const int minBucket = CheapestSplit( bb, cnt, R.area );
     uint32_t passing = 0;
     for ( int j = 0; j <= minBucket; ++j ) passing += static_cast< uint32_t >( cnt[j] );
     uint32_t cutoff = R.start + passing;
     R.dim |= static_cast< uint32_t >( minBucket ) << 8;
+    bool known = true;
     if ( cutoff == R.start || cutoff == R.end )
     {
         // every shape on one side: std::partition moved nothing; the range is halved where it lies (the reference
-        // itself recurses without end here, src/bvh.cpp:173-175)
+        // itself recurses without end here, src/bvh.cpp:173-175) and the halves' boxes have to be summed
         cutoff   = static_cast< uint32_t >( ( static_cast< uint64_t >( R.start ) + R.end ) / 2u );
         R.noMove = 1;
+        known    = false;
+    }
+    Box box0 = EmptyBox(), cbox0 = EmptyBox(), box1 = EmptyBox(), cbox1 = EmptyBox();
+    for ( int j = 0; j < kBuckets; ++j )
+    {
+        Union( j <= minBucket ? box0 : box1, bb[j] );
+        Union( j <= minBucket ? cbox0 : cbox1, cb[j] );
     }
     R.cutoff              = cutoff;
     const uint32_t second = R.slot + 2u * ( cutoff - R.start );
     nodes[8ull * R.slot + 6] = second;
-    NewRange( R.start, cutoff, R.slot + 1u, next, counters, small, &R.left );
-    NewRange( cutoff, R.end, second, next, counters, small, &R.right );
+    NewRange( R.start, cutoff, R.slot + 1u, known, box0, cbox0, nodes, next, counters, small, &R.left );
+    NewRange( cutoff, R.end, second, known, box1, cbox1, nodes, next, counters, small, &R.right );
 }
 
 // Level step 5: the predicate of std::partition (src/bvh.cpp:164-168) per shape, as the input of a prefix sum.
@@ -509,7 +637,7 @@ __global__ __launch_bounds__( kBlock ) void SwapKernel( float4* __restrict__ ite
     items[2 * b] = a0; items[2 * b + 1] = a1;
 }
 
-// --- ranges of at most four shapes: one thread finishes the subtree -------------------------------------------------
+// --- small ranges: one thread finishes the subtree -------------------------------------------------
 
 struct Shape
 {
@@ -578,54 +706,115 @@ __device__ void NthElement( Shape* v, int first, int nth, int last, int dim )
     InsertionSort( v, first, last, dim );
 }
 
-__global__ void SmallKernel( const float4* __restrict__ items, const SmallRange* __restrict__ small, uint32_t count, uint32_t* __restrict__ nodes,
-                             uint32_t* __restrict__ order )
+// One thread builds the subtree over a range of at most kThreadRange shapes the way the reference's recursion does,
+// in place: boxes in shape order, the bucketed split with std::partition's own two-pointer walk (libstdc++,
+// bits/stl_algo.h __partition for bidirectional iterators), nth_element on ranges of at most four.  Of the two halves
+// of a range the smaller is built first while the larger waits, so that few ranges ever wait at once.
+__global__ void SubtreeKernel( float4* __restrict__ items, const SmallRange* __restrict__ small, uint32_t count, uint32_t* __restrict__ nodes,
+                               uint32_t* __restrict__ order )
 {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if ( r >= count ) return;
-    const SmallRange R = small[r];
-    const int total    = static_cast< int >( R.end - R.start );
-    Shape v[kSmallRange];
-    for ( int k = 0; k < total; ++k )
+    constexpr int kWaiting = 8; // log2( kThreadRange ) + 1 is enough
+    uint32_t waitS[kWaiting], waitE[kWaiting], waitSlot[kWaiting];
+    int waiting = 0;
+    uint32_t s = small[r].start, e = small[r].end, slot = small[r].slot;
+    while ( true )
     {
-        const float4 lo = items[2ull * ( R.start + k )], hi = items[2ull * ( R.start + k ) + 1];
-        v[k].box   = Box{ { lo.x, lo.y, lo.z }, { hi.x, hi.y, hi.z } };
-        v[k].index = __float_as_uint( lo.w );
-    }
-    int stackS[4], stackE[4];
-    uint32_t stackSlot[4];
-    int top      = 0;
-    stackS[0]    = 0;
-    stackE[0]    = total;
-    stackSlot[0] = R.slot;
-    top          = 1;
-    while ( top > 0 )
-    {
-        --top;
-        const int s = stackS[top], e = stackE[top];
-        const uint32_t slot = stackSlot[top];
-        Box box = EmptyBox();
-        for ( int k = s; k < e; ++k ) Union( box, v[k].box );
-        if ( e - s == 1 ) // src/bvh.cpp:47-56
+        Box box = EmptyBox(), cbox = EmptyBox();
+        for ( uint32_t i = s; i < e; ++i )
         {
-            WriteNode( nodes, slot, box, R.start + s, 1u, 0u );
-            order[R.start + s] = v[s].index;
-            continue;
-        }
-        Box cbox = EmptyBox();
-        for ( int k = s; k < e; ++k )
-        {
+            const Box b = ItemBox( items, i );
+            Union( box, b );
             Box c;
-            for ( int q = 0; q < 3; ++q ) c.lo[q] = c.hi[q] = Centroid( v[k].box.lo[q], v[k].box.hi[q] );
+            for ( int q = 0; q < 3; ++q ) c.lo[q] = c.hi[q] = Centroid( b.lo[q], b.hi[q] );
             Union( cbox, c );
         }
+        if ( e - s == 1 ) // src/bvh.cpp:47-56
+        {
+            WriteNode( nodes, slot, box, s, 1u, 0u );
+            order[s] = __float_as_uint( items[2ull * s].w );
+            if ( waiting == 0 ) break;
+            --waiting;
+            s = waitS[waiting]; e = waitE[waiting]; slot = waitSlot[waiting];
+            continue;
+        }
         const int dim = LongestDimension( cbox );
-        const int nth = ( s + e ) / 2; // src/bvh.cpp:85-90,95-98: the middle element, counted from the array's start
-        NthElement( v, s, nth, e, dim );
-        const uint32_t second = slot + 2u * static_cast< uint32_t >( nth - s );
+        uint32_t cutoff;
+        if ( e - s <= kSmallRange ) // src/bvh.cpp:95-98: the middle element by nth_element
+        {
+            const int total = static_cast< int >( e - s );
+            Shape v[kSmallRange];
+            for ( int k = 0; k < total; ++k )
+            {
+                v[k].box   = ItemBox( items, s + k );
+                v[k].index = __float_as_uint( items[2ull * ( s + k )].w );
+            }
+            cutoff = static_cast< uint32_t >( ( static_cast< uint64_t >( s ) + e ) / 2u );
+            NthElement( v, 0, static_cast< int >( cutoff - s ), total, dim );
+            for ( int k = 0; k < total; ++k )
+            {
+                items[2ull * ( s + k )]     = float4{ v[k].box.lo[0], v[k].box.lo[1], v[k].box.lo[2], __uint_as_float( v[k].index ) };
+                items[2ull * ( s + k ) + 1] = float4{ v[k].box.hi[0], v[k].box.hi[1], v[k].box.hi[2], 0.0f };
+            }
+        }
+        else // src/bvh.cpp:100-169
+        {
+            Box bb[kBuckets];
+            int cnt[kBuckets];
+            for ( int b = 0; b < kBuckets; ++b )
+            {
+                bb[b]  = EmptyBox();
+                cnt[b] = 0;
+            }
+            const float cMin = cbox.lo[dim], cMax = cbox.hi[dim];
+            for ( uint32_t i = s; i < e; ++i )
+            {
+                const Box b = ItemBox( items, i );
+                const int q = BucketOf( Centroid( b.lo[dim], b.hi[dim] ), cMin, cMax );
+                cnt[q]++;
+                Union( bb[q], b );
+            }
+            const int minBucket = CheapestSplit( bb, cnt, SurfaceArea( box ) );
+            auto passes = [&]( uint32_t i ) {
+                const float4 lo = items[2ull * i], hi = items[2ull * i + 1];
+                const float c   = dim == 0 ? Centroid( lo.x, hi.x ) : dim == 1 ? Centroid( lo.y, hi.y ) : Centroid( lo.z, hi.z );
+                return BucketOf( c, cMin, cMax ) <= minBucket;
+            };
+            uint32_t first = s, last = e;
+            while ( true )
+            {
+                while ( first != last && passes( first ) ) ++first;
+                if ( first == last ) break;
+                --last;
+                while ( first != last && !passes( last ) ) --last;
+                if ( first == last ) break;
+                const float4 a0 = items[2ull * first], a1 = items[2ull * first + 1];
+                items[2ull * first]     = items[2ull * last];
+                items[2ull * first + 1] = items[2ull * last + 1];
+                items[2ull * last]      = a0;
+                items[2ull * last + 1]  = a1;
+                ++first;
+            }
+            cutoff = first;
+            if ( cutoff == s || cutoff == e ) cutoff = static_cast< uint32_t >( ( static_cast< uint64_t >( s ) + e ) / 2u ); // as in SplitKernel
+        }
+        const uint32_t second = slot + 2u * ( cutoff - s );
         WriteNode( nodes, slot, box, second, 0u, static_cast< uint32_t >( dim ) );
-        stackS[top] = nth; stackE[top] = e; stackSlot[top] = second; ++top;
-        stackS[top] = s;   stackE[top] = nth; stackSlot[top] = slot + 1u; ++top;
+        if ( cutoff - s <= e - cutoff )
+        {
+            waitS[waiting] = cutoff; waitE[waiting] = e; waitSlot[waiting] = second;
+            ++waiting;
+            e    = cutoff;
+            slot = slot + 1u;
+        }
+        else
+        {
+            waitS[waiting] = s; waitE[waiting] = cutoff; waitSlot[waiting] = slot + 1u;
+            ++waiting;
+            s    = cutoff;
+            slot = second;
+        }
     }
 }
 
@@ -679,8 +868,12 @@ int Build( int32_t device, const float* boxes, uint64_t n64, PtBvhNode* nodesOut
     const uint32_t n      = static_cast< uint32_t >( n64 );
     const uint32_t padded = ( ( n + 1u + 4u * kBlock - 1u ) / ( 4u * kBlock ) ) * ( 4u * kBlock ); // prefix sums: n + 1 words, whole blocks of uint4
     const uint32_t scanBlocks = padded / ( 4u * kBlock );
-    const uint32_t bigMax     = n / ( kSmallRange + 1u ) + 1u;
+    const uint32_t bigMax     = n / ( kThreadRange + 1u ) + 1u;
     const uint32_t itemBlocks = ( n + kBlock - 1u ) / kBlock;
+    // tiles of kBlock shapes per block of BucketKernel: many, so that few blocks add to the sums of the big ranges near
+    // the root, but not so many that the GPU's 256 compute units run out of blocks
+    const uint32_t tiles        = n >= ( 16u << 20 ) ? 16u : n >= ( 1u << 20 ) ? n >> 20 : 1u;
+    const uint32_t bucketBlocks = ( n + tiles * kBlock - 1u ) / ( tiles * kBlock );
 
     int deviceCount = 0;
     BVH_TRY( hipGetDeviceCount( &deviceCount ) );
@@ -699,7 +892,7 @@ int Build( int32_t device, const float* boxes, uint64_t n64, PtBvhNode* nodesOut
     BVH_TRY( dRanges[1].Alloc( sizeof( BigRange ) * static_cast< size_t >( bigMax ) ) );
     BVH_TRY( dBuckets.Alloc( sizeof( Buckets ) * static_cast< size_t >( bigMax ) ) );
     BVH_TRY( dSmall.Alloc( sizeof( SmallRange ) * static_cast< size_t >( n ) ) );
-    BVH_TRY( dCounters.Alloc( 8 ) );
+    BVH_TRY( dCounters.Alloc( 12 ) );
     BVH_TRY( dNodes.Alloc( 32ull * ( 2ull * n - 1ull ) ) );
     BVH_TRY( dOrder.Alloc( 4ull * n ) );
 
@@ -722,16 +915,18 @@ int Build( int32_t device, const float* boxes, uint64_t n64, PtBvhNode* nodesOut
     FillItemsKernel<<< itemBlocks, kBlock, 0, stream >>>( dBoxes.As< float >(), dItems.As< float4 >(), n );
     BVH_TRY( hipMemsetAsync( dSeg.p, 0, 4ull * n, stream ) );
 
-    uint32_t counts[2] = { 0, 0 }; // ranges of more than four shapes of the level, ranges of at most four from the level before
-    if ( n > kSmallRange )
+    uint32_t counts[3] = { 0, 0, 0 }; // ranges this level splits; small ranges that the level before left to single threads; ranges without a box yet
+    if ( n > kThreadRange )
     {
         BigRange root{};
         root.start = 0; root.end = n; root.slot = 0; root.cutoff = 0;
         root.left = root.right = kNone;
+        root.needReduce = 1;
         for ( int q = 0; q < 12; ++q ) root.acc[q] = q < 6 ? 0xFFFFFFFFu : 0u;
         BVH_TRY( hipMemcpyAsync( dRanges[0].p, &root, sizeof( root ), hipMemcpyHostToDevice, stream ) );
         BVH_TRY( hipStreamSynchronize( stream ) ); // `root` leaves scope
         counts[0] = 1;
+        counts[2] = 1;
     }
     else
     {
@@ -746,16 +941,24 @@ int Build( int32_t device, const float* boxes, uint64_t n64, PtBvhNode* nodesOut
     {
         if ( level >= kMaxLevels ) return Fail( PT_ERR_INVALID_SCENE, "the tree is deeper than 8192 levels" );
         if ( counts[1] )
-            SmallKernel<<< ( counts[1] + 255u ) / 256u, 256, 0, stream >>>( dItems.As< float4 >(), dSmall.As< SmallRange >(), counts[1], dNodes.As< uint32_t >(),
+            SubtreeKernel<<< ( counts[1] + 255u ) / 256u, 256, 0, stream >>>( dItems.As< float4 >(), dSmall.As< SmallRange >(), counts[1], dNodes.As< uint32_t >(),
                                                                                dOrder.As< uint32_t >() );
         if ( !counts[0] ) break;
         BigRange* now        = dRanges[cur].As< BigRange >();
         BigRange* next       = dRanges[cur ^ 1].As< BigRange >();
         const uint32_t rangeBlocks = ( counts[0] + 255u ) / 256u;
-        ReduceKernel<<< itemBlocks, kBlock, 0, stream >>>( dItems.As< float4 >(), dSeg.As< uint32_t >(), next, now, n, static_cast< int >( level ) );
-        AxisKernel<<< rangeBlocks, 256, 0, stream >>>( now, dBuckets.As< Buckets >(), counts[0], dNodes.As< uint32_t >() );
-        BucketKernel<<< itemBlocks, kBlock, 0, stream >>>( dItems.As< float4 >(), dSeg.As< uint32_t >(), now, dBuckets.As< Buckets >(), n );
-        BVH_TRY( hipMemsetAsync( dCounters.p, 0, 8, stream ) );
+        const uint32_t bucketWords = counts[0] * kBuckets * kBucketWords;
+        InitBucketsKernel<<< ( bucketWords + 255u ) / 256u, 256, 0, stream >>>( dBuckets.As< uint32_t >(), bucketWords );
+        int updateSeg = level > 0;
+        if ( counts[2] ) // the root, or halves of a range that was halved where it lay: their boxes are summed from the shapes
+        {
+            if ( updateSeg ) SegUpdateKernel<<< itemBlocks, kBlock, 0, stream >>>( dSeg.As< uint32_t >(), next, n );
+            updateSeg = 0;
+            ReduceKernel<<< itemBlocks, kBlock, 0, stream >>>( dItems.As< float4 >(), dSeg.As< uint32_t >(), now, n );
+            AxisKernel<<< rangeBlocks, 256, 0, stream >>>( now, counts[0], dNodes.As< uint32_t >() );
+        }
+        BucketKernel<<< bucketBlocks, kBlock, 0, stream >>>( dItems.As< float4 >(), dSeg.As< uint32_t >(), next, now, dBuckets.As< Buckets >(), n, tiles, updateSeg );
+        BVH_TRY( hipMemsetAsync( dCounters.p, 0, 12, stream ) );
         SplitKernel<<< rangeBlocks, 256, 0, stream >>>( now, dBuckets.As< Buckets >(), counts[0], dNodes.As< uint32_t >(), next, dSmall.As< SmallRange >(),
                                                          dCounters.As< uint32_t >() );
         FlagKernel<<< padded / kBlock, kBlock, 0, stream >>>( dItems.As< float4 >(), dSeg.As< uint32_t >(), now, dPrefix.As< uint32_t >(), n, padded );
@@ -766,7 +969,7 @@ int Build( int32_t device, const float* boxes, uint64_t n64, PtBvhNode* nodesOut
         SwapKernel<<< itemBlocks, kBlock, 0, stream >>>( dItems.As< float4 >(), dSeg.As< uint32_t >(), now, dPrefix.As< uint32_t >(), dFailing.As< uint32_t >(),
                                                           dPassing.As< uint32_t >(), n );
         BVH_TRY( hipGetLastError() );
-        BVH_TRY( hipMemcpy( counts, dCounters.p, 8, hipMemcpyDeviceToHost ) );
+        BVH_TRY( hipMemcpy( counts, dCounters.p, 12, hipMemcpyDeviceToHost ) );
         if ( counts[0] > bigMax || counts[1] > n ) return Fail( PT_ERR_DEVICE, "range lists overflowed" );
         cur ^= 1;
     }

@@ -1,9 +1,12 @@
-"""The GPU builder of the reference's SAH tree (pt_build_bvh) against the host builder (pth_build_bvh), which
-tests/test_oracle_vs_reference.py pins node for node against the reference's own BVH::Build.
+"""The GPU builder of the reference's SAH tree (pt_build_bvh) against the trees the reference's own BVH::Build made
+(tests/golden/golden_bvh.npz, golden_bvh_large.npz) and, on everything else, against the host builder (pth_build_bvh),
+which tests/test_host.py and tests/test_oracle_vs_reference.py pin node for node against the reference's.
 
 Bar: the shape order, every node's offset / shape count / axis bit-equal; the boxes equal as floats (a zero bound may
 differ in its sign: the reference keeps the sign of the first zero it meets, a parallel minimum cannot).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -30,6 +33,26 @@ def assert_same_tree(boxes, what):
         wrong = np.flatnonzero((nodes[field] != want_nodes[field]).any(axis=1))
         assert wrong.size == 0, f"{what}: node {wrong[0]} differs in {field}: {nodes[field][wrong[0]]} != {want_nodes[field][wrong[0]]}"
     return nodes, order
+
+
+def assert_equals_reference_tree(nodes, order, want_nodes, want_order, what):
+    assert np.array_equal(order, want_order), what
+    for field in ("offset", "num_shapes", "axis"):
+        assert np.array_equal(nodes[field], want_nodes[field]), f"{what}: {field}"
+    for field in ("aabb_min", "aabb_max"):
+        assert (nodes[field] == want_nodes[field]).all(), f"{what}: {field}"
+
+
+def test_matches_the_references_own_trees(scenes, golden):
+    """Directly against what the reference's BVH::Build produced: 4,000 triangles, and the two golden scenes."""
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_bvh_large.npz"))
+    tris = z["triangles"]
+    nodes, order = api.build_bvh(np.concatenate([tris.min(axis=1), tris.max(axis=1)], axis=1))
+    assert_equals_reference_tree(nodes, order, z["nodes"], z["order"], "4,000 triangles")
+    from test_oracle_vs_reference import shape_boxes
+    for name in ("cornell", "mixed"):
+        nodes, order = api.build_bvh(shape_boxes(scenes[name]))
+        assert_equals_reference_tree(nodes, order, golden["bvh"][f"{name}_sah_nodes"], golden["bvh"][f"{name}_sah_order"], name)
 
 
 @pytest.mark.parametrize("n", list(range(1, 41)) + [63, 64, 65, 100, 257, 1000, 1023, 1024, 1025, 4097])

@@ -24,6 +24,17 @@ def test_bvh_builder_matches_golden_reference_build(name, method, tag, scenes, g
         assert np.array_equal(nodes[field], want[field]), field
 
 
+def test_bvh_builder_matches_reference_build_of_4000_triangles():
+    """tests/golden/golden_bvh_large.npz (made by tests/golden/make_bvh_large_golden.py): the reference's own SAH tree over
+    4,000 triangles - bucketed splits of thousands of shapes, nth_element on the small ranges, tied centroids."""
+    z = np.load(os.path.join(ROOT, "tests", "golden", "golden_bvh_large.npz"))
+    tris, want = z["triangles"], z["nodes"]
+    nodes, order = host.build_bvh(np.concatenate([tris.min(axis=1), tris.max(axis=1)], axis=1), abi.PTH_SPLIT_SAH)
+    assert np.array_equal(order, z["order"])
+    for field in ("aabb_min", "aabb_max", "offset", "num_shapes", "axis"):
+        assert np.array_equal(nodes[field], want[field]), field
+
+
 def test_bvh_is_preorder_with_single_shape_leaves(scenes):
     s = scenes["cornell"]
     assert len(s.nodes) == 71 and len(s.prims) == 36       # what the reference reports for cornell.json
