@@ -431,12 +431,6 @@ __device__ __forceinline__ int CheapestSplit( const Box* bb, const int* cnt, flo
     return minBucket;
 }
 
-__device__ __forceinline__ Box ItemBox( const float4* items, uint32_t i )
-{
-    const float4 lo = items[2ull * i], hi = items[2ull * i + 1];
-    return Box{ { lo.x, lo.y, lo.z }, { hi.x, hi.y, hi.z } };
-}
-
 // A half of a split range becomes a range of the next level (with its box and centroid box, if the split knows
 // them) or, if it is small, the work of one thread.
 __device__ __forceinline__ void NewRange( uint32_t start, uint32_t end, uint32_t slot, bool known, const Box& box, const Box& cbox, uint32_t* nodes,
@@ -706,25 +700,45 @@ __device__ void NthElement( Shape* v, int first, int nth, int last, int dim )
     InsertionSort( v, first, last, dim );
 }
 
-// One thread builds the subtree over a range of at most kThreadRange shapes the way the reference's recursion does,
-// in place: boxes in shape order, the bucketed split with std::partition's own two-pointer walk (libstdc++,
-// bits/stl_algo.h __partition for bidirectional iterators), nth_element on ranges of at most four.  Of the two halves
-// of a range the smaller is built first while the larger waits, so that few ranges ever wait at once.
-__global__ void SubtreeKernel( float4* __restrict__ items, const SmallRange* __restrict__ small, uint32_t count, uint32_t* __restrict__ nodes,
-                               uint32_t* __restrict__ order )
+// One thread builds the subtree over a range of at most kThreadRange shapes the way the reference's recursion does:
+// boxes in shape order, the bucketed split with std::partition's own two-pointer walk (libstdc++, bits/stl_algo.h
+// __partition for bidirectional iterators), nth_element on ranges of at most four.  Of the two halves of a range
+// the smaller is built first while the larger waits, so that few ranges ever wait at once.  The thread's shapes
+// are copied to LDS first (word w of shape k of lane l at ( k * 7 + w ) * 64 + l: no two lanes share a bank more
+// than any 64-lane access must) and sorted there - a thread walks its range many times, and 64 threads doing that
+// 1 KB apart in memory would fetch a cache line for every 16 bytes they use.  Nothing is written back but nodes and
+// shape order: nobody reads the shapes of a finished range again.
+constexpr int kSubtreeWords = 7; // lo xyz, hi xyz, shape index
+__global__ __launch_bounds__( 64 ) void SubtreeKernel( const float4* __restrict__ items, const SmallRange* __restrict__ small, uint32_t count,
+                                                        uint32_t* __restrict__ nodes, uint32_t* __restrict__ order )
 {
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ uint32_t sShapes[kThreadRange * kSubtreeWords * 64];
+    const uint32_t r = blockIdx.x * 64u + threadIdx.x;
     if ( r >= count ) return;
+    uint32_t* mine = sShapes + threadIdx.x;
+    auto word  = [&]( uint32_t k, int w ) -> uint32_t& { return mine[( k * kSubtreeWords + w ) * 64u]; };
+    auto boxOf = [&]( uint32_t k ) {
+        return Box{ { __uint_as_float( word( k, 0 ) ), __uint_as_float( word( k, 1 ) ), __uint_as_float( word( k, 2 ) ) },
+                    { __uint_as_float( word( k, 3 ) ), __uint_as_float( word( k, 4 ) ), __uint_as_float( word( k, 5 ) ) } };
+    };
+    const uint32_t base = small[r].start, total = small[r].end - small[r].start;
+    for ( uint32_t k = 0; k < total; ++k )
+    {
+        const float4 lo = items[2ull * ( base + k )], hi = items[2ull * ( base + k ) + 1];
+        word( k, 0 ) = __float_as_uint( lo.x ); word( k, 1 ) = __float_as_uint( lo.y ); word( k, 2 ) = __float_as_uint( lo.z );
+        word( k, 3 ) = __float_as_uint( hi.x ); word( k, 4 ) = __float_as_uint( hi.y ); word( k, 5 ) = __float_as_uint( hi.z );
+        word( k, 6 ) = __float_as_uint( lo.w );
+    }
     constexpr int kWaiting = 8; // log2( kThreadRange ) + 1 is enough
     uint32_t waitS[kWaiting], waitE[kWaiting], waitSlot[kWaiting];
     int waiting = 0;
-    uint32_t s = small[r].start, e = small[r].end, slot = small[r].slot;
+    uint32_t s = 0, e = total, slot = small[r].slot; // positions relative to the range's first shape
     while ( true )
     {
         Box box = EmptyBox(), cbox = EmptyBox();
         for ( uint32_t i = s; i < e; ++i )
         {
-            const Box b = ItemBox( items, i );
+            const Box b = boxOf( i );
             Union( box, b );
             Box c;
             for ( int q = 0; q < 3; ++q ) c.lo[q] = c.hi[q] = Centroid( b.lo[q], b.hi[q] );
@@ -732,8 +746,8 @@ __global__ void SubtreeKernel( float4* __restrict__ items, const SmallRange* __r
         }
         if ( e - s == 1 ) // src/bvh.cpp:47-56
         {
-            WriteNode( nodes, slot, box, s, 1u, 0u );
-            order[s] = __float_as_uint( items[2ull * s].w );
+            WriteNode( nodes, slot, box, base + s, 1u, 0u );
+            order[base + s] = word( s, 6 );
             if ( waiting == 0 ) break;
             --waiting;
             s = waitS[waiting]; e = waitE[waiting]; slot = waitSlot[waiting];
@@ -743,19 +757,24 @@ __global__ void SubtreeKernel( float4* __restrict__ items, const SmallRange* __r
         uint32_t cutoff;
         if ( e - s <= kSmallRange ) // src/bvh.cpp:95-98: the middle element by nth_element
         {
-            const int total = static_cast< int >( e - s );
+            const int n = static_cast< int >( e - s );
             Shape v[kSmallRange];
-            for ( int k = 0; k < total; ++k )
+            for ( int k = 0; k < n; ++k )
             {
-                v[k].box   = ItemBox( items, s + k );
-                v[k].index = __float_as_uint( items[2ull * ( s + k )].w );
+                v[k].box   = boxOf( s + k );
+                v[k].index = word( s + k, 6 );
             }
-            cutoff = static_cast< uint32_t >( ( static_cast< uint64_t >( s ) + e ) / 2u );
-            NthElement( v, 0, static_cast< int >( cutoff - s ), total, dim );
-            for ( int k = 0; k < total; ++k )
+            // the middle of the range counted from the array's start: ( start + end ) / 2 with start = base + s, end = base + e
+            cutoff = static_cast< uint32_t >( ( 2ull * base + s + e ) / 2u - base );
+            NthElement( v, 0, static_cast< int >( cutoff - s ), n, dim );
+            for ( int k = 0; k < n; ++k )
             {
-                items[2ull * ( s + k )]     = float4{ v[k].box.lo[0], v[k].box.lo[1], v[k].box.lo[2], __uint_as_float( v[k].index ) };
-                items[2ull * ( s + k ) + 1] = float4{ v[k].box.hi[0], v[k].box.hi[1], v[k].box.hi[2], 0.0f };
+                for ( int q = 0; q < 3; ++q )
+                {
+                    word( s + k, q )     = __float_as_uint( v[k].box.lo[q] );
+                    word( s + k, 3 + q ) = __float_as_uint( v[k].box.hi[q] );
+                }
+                word( s + k, 6 ) = v[k].index;
             }
         }
         else // src/bvh.cpp:100-169
@@ -768,36 +787,34 @@ __global__ void SubtreeKernel( float4* __restrict__ items, const SmallRange* __r
                 cnt[b] = 0;
             }
             const float cMin = cbox.lo[dim], cMax = cbox.hi[dim];
+            auto bucketOf = [&]( uint32_t i ) {
+                return BucketOf( Centroid( __uint_as_float( word( i, dim ) ), __uint_as_float( word( i, 3 + dim ) ) ), cMin, cMax );
+            };
             for ( uint32_t i = s; i < e; ++i )
             {
-                const Box b = ItemBox( items, i );
-                const int q = BucketOf( Centroid( b.lo[dim], b.hi[dim] ), cMin, cMax );
+                const int q = bucketOf( i );
                 cnt[q]++;
-                Union( bb[q], b );
+                Union( bb[q], boxOf( i ) );
             }
             const int minBucket = CheapestSplit( bb, cnt, SurfaceArea( box ) );
-            auto passes = [&]( uint32_t i ) {
-                const float4 lo = items[2ull * i], hi = items[2ull * i + 1];
-                const float c   = dim == 0 ? Centroid( lo.x, hi.x ) : dim == 1 ? Centroid( lo.y, hi.y ) : Centroid( lo.z, hi.z );
-                return BucketOf( c, cMin, cMax ) <= minBucket;
-            };
             uint32_t first = s, last = e;
             while ( true )
             {
-                while ( first != last && passes( first ) ) ++first;
+                while ( first != last && bucketOf( first ) <= minBucket ) ++first;
                 if ( first == last ) break;
                 --last;
-                while ( first != last && !passes( last ) ) --last;
+                while ( first != last && !( bucketOf( last ) <= minBucket ) ) --last;
                 if ( first == last ) break;
-                const float4 a0 = items[2ull * first], a1 = items[2ull * first + 1];
-                items[2ull * first]     = items[2ull * last];
-                items[2ull * first + 1] = items[2ull * last + 1];
-                items[2ull * last]      = a0;
-                items[2ull * last + 1]  = a1;
+                for ( int w = 0; w < kSubtreeWords; ++w )
+                {
+                    const uint32_t t = word( first, w );
+                    word( first, w ) = word( last, w );
+                    word( last, w )  = t;
+                }
                 ++first;
             }
             cutoff = first;
-            if ( cutoff == s || cutoff == e ) cutoff = static_cast< uint32_t >( ( static_cast< uint64_t >( s ) + e ) / 2u ); // as in SplitKernel
+            if ( cutoff == s || cutoff == e ) cutoff = static_cast< uint32_t >( ( 2ull * base + s + e ) / 2u - base ); // as in SplitKernel
         }
         const uint32_t second = slot + 2u * ( cutoff - s );
         WriteNode( nodes, slot, box, second, 0u, static_cast< uint32_t >( dim ) );
@@ -941,7 +958,7 @@ int Build( int32_t device, const float* boxes, uint64_t n64, PtBvhNode* nodesOut
     {
         if ( level >= kMaxLevels ) return Fail( PT_ERR_INVALID_SCENE, "the tree is deeper than 8192 levels" );
         if ( counts[1] )
-            SubtreeKernel<<< ( counts[1] + 255u ) / 256u, 256, 0, stream >>>( dItems.As< float4 >(), dSmall.As< SmallRange >(), counts[1], dNodes.As< uint32_t >(),
+            SubtreeKernel<<< ( counts[1] + 63u ) / 64u, 64, 0, stream >>>( dItems.As< float4 >(), dSmall.As< SmallRange >(), counts[1], dNodes.As< uint32_t >(),
                                                                                dOrder.As< uint32_t >() );
         if ( !counts[0] ) break;
         BigRange* now        = dRanges[cur].As< BigRange >();
