@@ -36,10 +36,10 @@ namespace
 constexpr uint32_t kNone       = 0xFFFFFFFFu;
 constexpr int kBuckets         = 12; // src/bvh.cpp:102
 constexpr uint32_t kSmallRange = 4;  // src/bvh.cpp:95,150
-constexpr uint32_t kThreadRange = 32; // a range of at most this many shapes is finished by one thread
+constexpr uint32_t kThreadRange = 16; // a range of at most this many shapes is finished by one thread
 constexpr int kBlock           = 1024;
 constexpr int kWaves           = kBlock / 64;
-constexpr int kMaxRuns         = 32; // ranges a block may meet and still combine their sums in LDS
+constexpr int kMaxRuns         = 64; // ranges a block may meet and still combine their sums in LDS
 constexpr float kFltMax        = 3.402823466e+38f; // the empty box: min = +this, max = -this (src/aabb.cpp:6-10)
 constexpr uint32_t kMaxLevels  = 8192;
 

@@ -137,6 +137,27 @@ def test_benchmark_scenes():
         assert_same_tree(boxes[rng.permutation(len(boxes))], what)
 
 
+def test_scenes_built_through_the_host_library_hook():
+    """host.use_gpu_bvh_builder: the host library hands the SAH trees of its scenes to pt_build_bvh - same scene."""
+    def scene_arrays():
+        hs = host.HostScene.knot(seed=2, triangles=20000)
+        try:
+            d = hs.to_data()
+            return d.nodes.copy(), d.prims.copy()
+        finally:
+            hs.close()
+    want_nodes, want_prims = scene_arrays()
+    host.use_gpu_bvh_builder(0)
+    try:
+        nodes, prims = scene_arrays()
+    finally:
+        host.use_gpu_bvh_builder(None)
+    assert np.array_equal(prims, want_prims)
+    for field in ("offset", "num_shapes", "axis"):
+        assert np.array_equal(nodes[field], want_nodes[field]), field
+    assert (nodes["aabb_min"] == want_nodes["aabb_min"]).all() and (nodes["aabb_max"] == want_nodes["aabb_max"]).all()
+
+
 def test_two_million_triangle_soup():
     rng = np.random.default_rng(3)
     n = 2_000_000
