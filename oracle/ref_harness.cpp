@@ -40,6 +40,7 @@
 #include "pt_flatten.hpp"
 #define PT_BINDING_NO_LINK // the GPU library is handed over at run time, see ref_render_gpu
 #include "pt_render_binding.hpp"
+#include "pt_bvh_binding.hpp"
 
 #include <cstdio>
 #include <cstring>
@@ -462,6 +463,25 @@ int ref_bvh_build( const PtSceneDesc* d, int splitMethod, PtBvhNode* nodes_out, 
     }
     std::memcpy( static_cast< void* >( nodes_out ), bvh.nodes, nodes * sizeof( PtBvhNode ) );
     for ( uint64_t k = 0; k < nodes; ++k ) nodes_out[k].pad = 0; // the reference leaves this byte uninitialised
+    for ( size_t k = 0; k < bvh.shapes.size(); ++k ) order_out[k] = r.primIndex.at( bvh.shapes[k].get() );
+    *num_nodes_out = nodes;
+    return 0;
+}
+
+// The same through the reference-side binding of the GPU builder (oracle/pt_bvh_binding.hpp): a PT::BVH filled by
+// `build` (pt_build_bvh, passed as a pointer because this library also loads where there is no GPU) instead of by
+// BVH::Build, read back the same way.
+int ref_bvh_build_with( const PtSceneDesc* d, void* build, int device, PtBvhNode* nodes_out, uint32_t* order_out, uint64_t* num_nodes_out )
+{
+    RefScene r;
+    std::string err;
+    if ( !BuildShapes( d, r, err ) ) return Fail( err );
+    PT::BVH bvh;
+    bvh.splitMethod = PT::BVH::SplitMethod::SAH;
+    std::vector< std::shared_ptr< PT::Shape > > list = r.ordered;
+    if ( !PT::BuildOnGpu( bvh, list, reinterpret_cast< PT::PtBuildBvhFn >( build ), device ) ) return Fail( "BuildOnGpu: the builder failed" );
+    const uint64_t nodes = 2 * bvh.shapes.size() - 1;
+    std::memcpy( static_cast< void* >( nodes_out ), bvh.nodes, nodes * sizeof( PtBvhNode ) );
     for ( size_t k = 0; k < bvh.shapes.size(); ++k ) order_out[k] = r.primIndex.at( bvh.shapes[k].get() );
     *num_nodes_out = nodes;
     return 0;

@@ -158,6 +158,24 @@ def test_scenes_built_through_the_host_library_hook():
     assert (nodes["aabb_min"] == want_nodes["aabb_min"]).all() and (nodes["aabb_max"] == want_nodes["aabb_max"]).all()
 
 
+def test_reference_bvh_object_filled_by_the_gpu_builder(scenes):
+    """The reference's own PT::BVH, compiled from its sources, with the binding a maintainer would put into
+    BVH::Build (oracle/pt_bvh_binding.hpp) calling pt_build_bvh: nodes and BVH::shapes as BVH::Build leaves them."""
+    from oracle import ref
+    if not ref.available():
+        pytest.skip("oracle/_ref/libptref.so not built")
+    from geometry_cases import triangle_scene
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_bvh_large.npz"))
+    big = triangle_scene(z["triangles"])
+    big.prims["index"] = np.arange(len(big.prims), dtype=np.uint32)
+    for what, scene in (("cornell", scenes["cornell"]), ("mixed", scenes["mixed"]), ("4,000 triangles", big)):
+        desc = scene.to_desc()
+        want_nodes, want_order = ref.bvh_build(desc, abi.PTH_SPLIT_SAH)
+        nodes, order = ref.bvh_build_with(desc, api.lib().pt_build_bvh)
+        nodes["pad"] = 0
+        assert_equals_reference_tree(nodes, order, want_nodes, want_order, what)
+
+
 def test_two_million_triangle_soup():
     rng = np.random.default_rng(3)
     n = 2_000_000
