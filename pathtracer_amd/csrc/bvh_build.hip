@@ -13,10 +13,17 @@
 //   * std::partition over a range is a fixed permutation: the k-th element from the left that fails the predicate and
 //     lies before the partition point changes places with the k-th element from the right that passes it and lies
 //     behind - positions a prefix sum of the predicate gives to every element at once;
-//   * ranges of at most 32 shapes are finished by one thread each, which walks the reference's recursion itself, with
+//   * the bucket sums of a range (count, box, centroid box per bucket) hold, as unions over the buckets on either
+//     side of the chosen split, the boxes and centroid boxes of its two halves: one pass over the shapes per level
+//     feeds both the split of this level and the axes of the next;
+//   * ranges of at most 16 shapes are finished by one thread each, which walks the reference's recursion itself, with
 //     the element moves of libstdc++'s std::partition and std::nth_element (GCC 11; on at most four elements: one
 //     median-of-three partition step for four, then insertion sort).
 // All arithmetic is float32 in the reference's operation order, compiled without contraction.
+//
+// Per level: BucketKernel (shapes) -> SplitKernel (ranges) -> FlagKernel, three scan kernels, PartnerKernel,
+// SwapKernel (shapes); SubtreeKernel for the small ranges the level before set aside; one 12-byte read-back tells
+// the host how many ranges the next level has.
 #include "pt_api.h"
 
 #include <hip/hip_runtime.h>
