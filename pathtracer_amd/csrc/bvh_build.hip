@@ -842,13 +842,18 @@ __global__ __launch_bounds__( 64 ) void SubtreeKernel( const float4* __restrict_
     }
 }
 
-__global__ void FillItemsKernel( const float* __restrict__ boxes, float4* __restrict__ items, uint32_t n )
+// Shapes in scene order; *notFinite is set if a bound is an infinity or a NaN (the sums above order floats as
+// integers, which has no place for a NaN).
+__global__ void FillItemsKernel( const float* __restrict__ boxes, float4* __restrict__ items, uint32_t n, uint32_t* __restrict__ notFinite )
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if ( i >= n ) return;
     const float* b   = boxes + 6ull * i;
     items[2ull * i]     = float4{ b[0], b[1], b[2], __uint_as_float( i ) };
     items[2ull * i + 1] = float4{ b[3], b[4], b[5], 0.0f };
+    bool finite = true;
+    for ( int k = 0; k < 6; ++k ) finite = finite && fabsf( b[k] ) <= kFltMax;
+    if ( !finite ) atomicOr( notFinite, 1u );
 }
 
 struct Dev
@@ -887,8 +892,6 @@ int Build( int32_t device, const float* boxes, uint64_t n64, PtBvhNode* nodesOut
 {
     if ( !boxes || !nodesOut || !orderOut || n64 == 0 ) return Fail( PT_ERR_INVALID_ARG, "null pointer or no shapes" );
     if ( n64 > 0x3FFFFFFFull ) return Fail( PT_ERR_INVALID_ARG, "too many shapes for 32-bit node offsets" );
-    for ( uint64_t k = 0; k < 6 * n64; ++k )
-        if ( !std::isfinite( boxes[k] ) ) return Fail( PT_ERR_INVALID_SCENE, "a box has a bound that is not finite" );
     const uint32_t n      = static_cast< uint32_t >( n64 );
     const uint32_t padded = ( ( n + 1u + 4u * kBlock - 1u ) / ( 4u * kBlock ) ) * ( 4u * kBlock ); // prefix sums: n + 1 words, whole blocks of uint4
     const uint32_t scanBlocks = padded / ( 4u * kBlock );
@@ -936,7 +939,13 @@ int Build( int32_t device, const float* boxes, uint64_t n64, PtBvhNode* nodesOut
 
     BVH_TRY( hipMemcpy( dBoxes.p, boxes, 24ull * n, hipMemcpyHostToDevice ) );
     BVH_TRY( hipEventRecord( t0, stream ) );
-    FillItemsKernel<<< itemBlocks, kBlock, 0, stream >>>( dBoxes.As< float >(), dItems.As< float4 >(), n );
+    BVH_TRY( hipMemsetAsync( dCounters.p, 0, 12, stream ) );
+    FillItemsKernel<<< itemBlocks, kBlock, 0, stream >>>( dBoxes.As< float >(), dItems.As< float4 >(), n, dCounters.As< uint32_t >() );
+    {
+        uint32_t notFinite = 0;
+        BVH_TRY( hipMemcpy( &notFinite, dCounters.p, 4, hipMemcpyDeviceToHost ) );
+        if ( notFinite ) return Fail( PT_ERR_INVALID_SCENE, "a box has a bound that is not finite" );
+    }
     BVH_TRY( hipMemsetAsync( dSeg.p, 0, 4ull * n, stream ) );
 
     uint32_t counts[3] = { 0, 0, 0 }; // ranges this level splits; small ranges that the level before left to single threads; ranges without a box yet
