@@ -15,7 +15,7 @@ traversal = sys.argv[2] if len(sys.argv) > 2 else None
 
 
 def short(name):
-    name = name.split("(")[0].replace("ptd::", "").replace("void ", "")
+    name = name.replace("(anonymous namespace)::", "").split("(")[0].replace("ptd::", "").replace("void ", "")
     return name.strip()
 
 
