@@ -264,6 +264,19 @@ __global__ void InitBucketsKernel( uint32_t* __restrict__ words, uint32_t count 
     words[k]            = ( word >= 1 && word <= 6 ) ? 0xFFFFFFFFu : 0u; // count 0, minima at the top, maxima at the bottom
 }
 
+// One shape into the sums of its bucket in LDS.  A bound that does not lower a minimum (raise a maximum) as it reads
+// now cannot do so later either, the sums only move one way: the plain read first spares most of the atomics, which
+// pile up on few addresses otherwise.
+__device__ __forceinline__ void AddToBucket( uint32_t* w, const uint32_t* v )
+{
+    atomicAdd( w, 1u );
+    const volatile uint32_t* now = w;
+    for ( int k = 0; k < 6; ++k )
+        if ( v[k] < now[1 + k] ) atomicMin( w + 1 + k, v[k] );
+    for ( int k = 6; k < 12; ++k )
+        if ( v[k] > now[1 + k] ) atomicMax( w + 1 + k, v[k] );
+}
+
 // Level step 1 (src/bvh.cpp:104-112, and for the level after: src/bvh.cpp:41-45,62-70): every shape moves on to its
 // half of its old range (updateSeg), finds its bucket along its range's split axis and adds itself to the bucket's
 // count, box and centroid box.  The unions of the buckets on either side of the split that SplitKernel picks are
@@ -318,11 +331,9 @@ __global__ __launch_bounds__( kBlock ) void BucketKernel( const float4* __restri
             const float cx = Centroid( lo.x, hi.x ), cy = Centroid( lo.y, hi.y ), cz = Centroid( lo.z, hi.z );
             const int b    = BucketOf( dim == 0 ? cx : dim == 1 ? cy : cz, cMin, cMax );
             uint32_t* w    = sBk + ( wave * kBuckets + b ) * kBucketWords;
-            atomicAdd( w, 1u );
-            atomicMin( w + 1, Enc( lo.x ) ); atomicMin( w + 2, Enc( lo.y ) ); atomicMin( w + 3, Enc( lo.z ) );
-            atomicMin( w + 4, Enc( cx ) );   atomicMin( w + 5, Enc( cy ) );   atomicMin( w + 6, Enc( cz ) );
-            atomicMax( w + 7, Enc( hi.x ) ); atomicMax( w + 8, Enc( hi.y ) ); atomicMax( w + 9, Enc( hi.z ) );
-            atomicMax( w + 10, Enc( cx ) );  atomicMax( w + 11, Enc( cy ) );  atomicMax( w + 12, Enc( cz ) );
+            const uint32_t v[12] = { Enc( lo.x ), Enc( lo.y ), Enc( lo.z ), Enc( cx ), Enc( cy ), Enc( cz ),
+                                     Enc( hi.x ), Enc( hi.y ), Enc( hi.z ), Enc( cx ), Enc( cy ), Enc( cz ) };
+            AddToBucket( w, v );
         }
         __syncthreads();
         if ( threadIdx.x < kBuckets * kBucketWords )
@@ -379,9 +390,7 @@ __global__ __launch_bounds__( kBlock ) void BucketKernel( const float4* __restri
             if ( r != kNone )
             {
                 uint32_t* w = sBk + ( run * kBuckets + b ) * kBucketWords;
-                atomicAdd( w, 1u );
-                for ( int k = 0; k < 6; ++k ) atomicMin( w + 1 + k, v[k] );
-                for ( int k = 6; k < 12; ++k ) atomicMax( w + 1 + k, v[k] );
+                AddToBucket( w, v );
             }
             __syncthreads();
             for ( uint32_t k = threadIdx.x; k < runs * kBuckets * kBucketWords; k += kBlock )
