@@ -65,7 +65,7 @@ def parse():
     p.add_argument("--triangles", type=int, default=262267)
     p.add_argument("--texture-size", type=int, default=1024)
     p.add_argument("--seed", type=int, default=0)
-    p.add_argument("--traversal", choices=("ordered", "reference"), default="ordered",
+    p.add_argument("--traversal", choices=("wide", "ordered", "reference"), default="ordered",
                    help="child visiting order of the BVH traversal: front to back (default; same hits and film, fewer node "
                         "visits) or the reference's first-child-first order (counters equal to the CPU's)")
     p.add_argument("--scene-flags", type=int, default=0, help="PT_SCENE_* flags for pt_upload_scene (measurement switches)")
@@ -126,7 +126,8 @@ def main():
     spp_step = args.spp_per_step
     strong = args.scaling == "strong"
     spp_total = spp_step * (1 if strong else world) * (args.steps + args.warmup)
-    ordered = args.traversal == "ordered"
+    wide = args.traversal == "wide"
+    ordered = args.traversal == "ordered" or wide
 
     def run_step(step, profile):
         if strong:   # this rank's share of the step's samples of the frame
@@ -136,7 +137,7 @@ def main():
             first = (step * world + rank) * spp_step
             last = first + spp_step
         if last > first:
-            dev.render(spp_total, first, last, seed=args.seed, accumulate=True, profile=profile, ordered=ordered)
+            dev.render(spp_total, first, last, seed=args.seed, accumulate=True, profile=profile, ordered=ordered, wide=wide)
 
     # CPU baseline beside the GPU number, rank 0 at N = 1 only, before the GPU's warm-up: the reference's own compiled
     # Li / BVH / shape code (oracle/_ref/libptref.so, built from /root/reference in the build container) when that

@@ -153,9 +153,12 @@ enum
     PT_SCENE_NO_PARALLEL_SHADOWS = 1u << 3, /* do not build the light-space node layout that PT_RENDER_ORDERED uses
                                              for the shadow rays of a scene lit by one directional light (same
                                              picture either way; for measurements)                                     */
-    PT_SCENE_NO_ORDERED_LAYOUT = 1u << 2  /* do not build the second node layout that PT_RENDER_ORDERED and
+    PT_SCENE_NO_ORDERED_LAYOUT = 1u << 2, /* do not build the second node layout that PT_RENDER_ORDERED and
                                             PT_TRAVERSAL_ORDERED need (64 bytes of device memory per node); those
                                             then fail with PT_ERR_STATE                                               */
+    PT_SCENE_NO_WIDE_LAYOUT = 1u << 4     /* do not build the eight-wide node layout that PT_RENDER_WIDE and
+                                            PT_TRAVERSAL_WIDE need (about 25 bytes per node of the tree and a second
+                                            copy of the 64-byte primitive records); those then fail with PT_ERR_STATE   */
 };
 
 /* Everything PathTracer::Render reads from Scene (src/scene.hpp:27-37). */
@@ -212,9 +215,11 @@ enum
 {
     PT_RENDER_ACCUMULATE = 1u << 0, /* keep the film of earlier pt_render calls and add to it          */
     PT_RENDER_PROFILE    = 1u << 1, /* bracket every kernel class with events (PtStats::kernel_ms)     */
-    PT_RENDER_ORDERED    = 1u << 2  /* front-to-back traversal, see PT_TRAVERSAL_ORDERED; in a scene lit by one
+    PT_RENDER_ORDERED    = 1u << 2, /* front-to-back traversal, see PT_TRAVERSAL_ORDERED; in a scene lit by one
                                        directional light the shadow rays, all parallel, are traced in the light's
                                        space (same occlusion answers, other node counts)                          */
+    PT_RENDER_WIDE       = 1u << 3  /* PT_RENDER_ORDERED with the closest hits found over the eight-wide layout, see
+                                       PT_TRAVERSAL_WIDE: the same film, a fifth of the node visits                  */
 };
 
 /* Order in which a ray visits the children of an inner BVH node.
@@ -229,11 +234,18 @@ enum
  *   coincident surfaces, shared edges: whether a box is culled by a hit found earlier can hinge on one ulp).  The
  *   ordered pass keeps everything within a factor 1 + 2^-12 of the closest distance alive, and a ray that saw a
  *   second hit inside that band is traced again in the reference's order (PtStats::rays_redone).  Same primitive, t,
- *   u, v as PT_TRAVERSAL_REFERENCE; the node and test counters differ. */
+ *   u, v as PT_TRAVERSAL_REFERENCE; the node and test counters differ.
+ * PT_TRAVERSAL_WIDE: over the tree collapsed into nodes of up to eight children whose boxes are stored as 8-bit offsets
+ *   on a grid over the node's box, rounded outwards; children are visited front to back by the octant of the ray's
+ *   direction, with a short stack per ray.  The quantised boxes only select candidates: a primitive counts if the
+ *   reference's own test of its leaf's box (src/bvh.cpp:242) passes, and the rules of PT_TRAVERSAL_ORDERED about hits
+ *   within rounding of one another apply.  Same primitive, t, u, v and occlusion answers as PT_TRAVERSAL_REFERENCE;
+ *   nodes_visited counts wide nodes. */
 enum
 {
     PT_TRAVERSAL_REFERENCE = 0,
-    PT_TRAVERSAL_ORDERED   = 1
+    PT_TRAVERSAL_ORDERED   = 1,
+    PT_TRAVERSAL_WIDE      = 2
 };
 
 typedef struct PtRenderParams

@@ -51,6 +51,7 @@ struct PtoScene
     int num_blocks;
     int draws_per_bounce;
     uint32_t traversal; /* PT_TRAVERSAL_* */
+    uint8_t* sphere_below; /* per node: its subtree holds a sphere (front-to-back order only), or NULL: no spheres */
 };
 
 static _Thread_local char g_error[256];
@@ -94,6 +95,23 @@ int pto_scene_create( const PtSceneDesc* desc, PtoScene** out )
     for ( uint64_t i = 0; i < desc->num_lights; ++i )
         if ( desc->lights[i].type == PT_LIGHT_AREA ) area += desc->lights[i].n_samples;
     s->draws_per_bounce = 2 * area + 2;
+    s->sphere_below = NULL;
+    if ( desc->num_spheres > 0 )
+    {
+        /* children lie behind their parent in the pre-order array: one backward pass */
+        uint8_t* below = (uint8_t*)calloc( desc->num_nodes, 1 );
+        if ( !below ) { pto_scene_destroy( s ); return fail( "pto_scene_create: out of memory" ); }
+        s->blocks[s->num_blocks++] = below;
+        for ( uint64_t k = desc->num_nodes; k-- > 0; )
+        {
+            const PtBvhNode* n = &s->d.nodes[k];
+            if ( n->num_shapes > 0 )
+                for ( int p = n->offset; p < n->offset + n->num_shapes; ++p ) below[k] |= s->d.prims[p].type == PT_PRIM_SPHERE;
+            else
+                below[k] = below[k + 1] | below[n->offset];
+        }
+        s->sphere_below = below;
+    }
     *out = s;
     return 0;
 }
@@ -116,7 +134,7 @@ void pto_scene_destroy( PtoScene* s )
 
 /* intersect::RayAABBFastest, src/intersection_tests.cpp:91-110.  Comparisons, not min/max: a NaN slab value
  * (0 * inf) makes every comparison false, so the test passes. */
-static int ray_aabb_cmp( v3 o, v3 inv, const int neg[3], const float* bmin, const float* bmax, float maxT, int inclusive )
+static int ray_aabb_entry( v3 o, v3 inv, const int neg[3], const float* bmin, const float* bmax, float maxT, int inclusive, float* entry )
 {
     float tMin  = ( ( neg[0] ? bmax : bmin )[0] - o.x ) * inv.x;
     float tMax  = ( ( 1 - neg[0] ? bmax : bmin )[0] - o.x ) * inv.x;
@@ -131,7 +149,13 @@ static int ray_aabb_cmp( v3 o, v3 inv, const int neg[3], const float* bmin, cons
     if ( tzMin > tMin ) tMin = tzMin;
     if ( tzMax < tMax ) tMax = tzMax;
     /* inclusive: the front-to-back order's test (tMin <= maxT), not the reference's */
+    if ( entry ) *entry = tMin;
     return ( inclusive ? tMin <= maxT : tMin < maxT ) && ( tMax > 0 );
+}
+
+static int ray_aabb_cmp( v3 o, v3 inv, const int neg[3], const float* bmin, const float* bmax, float maxT, int inclusive )
+{
+    return ray_aabb_entry( o, inv, neg, bmin, bmax, maxT, inclusive, NULL );
 }
 
 static int ray_aabb( v3 o, v3 inv, const int neg[3], const float* bmin, const float* bmax, float maxT )
@@ -207,10 +231,15 @@ static void triangle_vertices( const PtSceneDesc* d, const PtTriangle* tri, size
 /* Triangle::Intersect (src/shapes.cpp:117-134) / Sphere::Intersect (src/shapes.cpp:52-76): test, and on an
  * accepted hit replace the hit record. */
 #define PTO_BAND ( 1.0f + 1.0f / 4096.0f ) /* front-to-back order: hits this close to the closest one are "ambiguous" */
+#define PTO_TRUST ( 1.0f + 1.0f / 16384.0f ) /* a hit this far in front of its own leaf box is not to be reasoned with */
 
 /* ambiguous == NULL: the reference's test.  Otherwise (front-to-back order): hits up to PTO_BAND times the closest
- * distance so far are looked at, and *ambiguous tells whether a second hit lies within that band of the closest. */
-static int shape_intersect_band( const PtSceneDesc* d, uint32_t prim, v3 o, v3 dir, Hit* hit, TravCount* cnt, int* ambiguous )
+ * distance so far are looked at, and *ambiguous tells whether a second hit lies within that band of the closest
+ * (bit 0).  Bit 1: a hit whose distance lies in front of the point where the ray enters the primitive's own leaf box
+ * (`entry`) by more than rounding of the box test explains - a primitive test that has lost its precision (a sphere
+ * seen from ten thousand radii away, a triangle met at a millionth of a degree).  The band argument rests on a hit
+ * lying inside its boxes, so such a ray is traced in the reference's order from scratch. */
+static int shape_intersect_band( const PtSceneDesc* d, uint32_t prim, v3 o, v3 dir, Hit* hit, TravCount* cnt, int* ambiguous, float entry )
 {
     const PtPrim* p = &d->prims[prim];
     const float limit = ambiguous ? hit->t * PTO_BAND : hit->t;
@@ -224,8 +253,9 @@ static int shape_intersect_band( const PtSceneDesc* d, uint32_t prim, v3 o, v3 d
         if ( !ray_triangle( o, dir, ld3( d->vertices + 3 * i[0] ), ld3( d->vertices + 3 * i[1] ), ld3( d->vertices + 3 * i[2] ), &t, &u, &v, limit ) ) return 0;
         if ( ambiguous )
         {
-            if ( !( t < hit->t ) ) { *ambiguous = 1; return 0; }
-            *ambiguous = hit->t <= t * PTO_BAND;
+            if ( entry > t * PTO_TRUST ) *ambiguous |= 2;
+            if ( !( t < hit->t ) ) { *ambiguous |= 1; return 0; }
+            *ambiguous = ( *ambiguous & 2 ) | ( hit->t <= t * PTO_BAND );
         }
         float w        = 1 - u - v;
         hit->t         = t;
@@ -249,8 +279,9 @@ static int shape_intersect_band( const PtSceneDesc* d, uint32_t prim, v3 o, v3 d
     if ( !ray_sphere( lo, ld, V( 0, 0, 0 ), 1.0f, &t, limit ) ) return 0;
     if ( ambiguous )
     {
-        if ( !( t < hit->t ) ) { *ambiguous = 1; return 0; }
-        *ambiguous = hit->t <= t * PTO_BAND;
+        if ( entry > t * PTO_TRUST ) *ambiguous |= 2;
+        if ( !( t < hit->t ) ) { *ambiguous |= 1; return 0; }
+        *ambiguous = ( *ambiguous & 2 ) | ( hit->t <= t * PTO_BAND );
     }
     hit->t        = t;
     hit->material = s->material;
@@ -271,7 +302,7 @@ static int shape_intersect_band( const PtSceneDesc* d, uint32_t prim, v3 o, v3 d
 
 static int shape_intersect( const PtSceneDesc* d, uint32_t prim, v3 o, v3 dir, Hit* hit, TravCount* cnt )
 {
-    return shape_intersect_band( d, prim, o, dir, hit, cnt, NULL );
+    return shape_intersect_band( d, prim, o, dir, hit, cnt, NULL, 0.0f );
 }
 
 /* Triangle::TestIfHit / Sphere::TestIfHit (src/shapes.cpp:136-141, 78-82): the sphere is tested in world space */
@@ -368,7 +399,7 @@ static int bvh_occluded( const PtSceneDesc* d, v3 o, v3 dir, float tMax, TravCou
  * alive (boxes entered with tMin <= PTO_BAND * t) and, when a second hit lay inside that band, runs the reference's
  * own order afterwards and returns its answer; the counters are the sums of both passes.  A plain stack of far
  * children here; the GPU side follows per-octant links instead, so equal per-ray counters check both. */
-static int bvh_intersect_ordered( const PtSceneDesc* d, v3 o, v3 dir, Hit* hit, TravCount* cnt )
+static int bvh_intersect_ordered( const PtSceneDesc* d, const uint8_t* sphere_below, v3 o, v3 dir, Hit* hit, TravCount* cnt )
 {
     int stack[128];
     int node = 0, top = 0, ambiguous = 0;
@@ -379,11 +410,16 @@ static int bvh_intersect_ordered( const PtSceneDesc* d, v3 o, v3 dir, Hit* hit, 
     {
         const PtBvhNode* n = &d->nodes[node];
         cnt->nodes++;
-        if ( ray_aabb_cmp( o, inv, neg, n->aabb_min, n->aabb_max, hit->t * PTO_BAND, 1 ) )
+        float entry;
+        /* a box with a sphere inside is entered whatever has been found: the sphere test loses its precision with the
+         * distance of the origin (it runs in the sphere's own space) long before the box test does, and a sphere
+         * hit the reference computes in front of the sphere's box must be seen here to be told apart */
+        const float limit = sphere_below && sphere_below[node] ? INFINITY : hit->t * PTO_BAND;
+        if ( ray_aabb_entry( o, inv, neg, n->aabb_min, n->aabb_max, limit, 1, &entry ) )
         {
             if ( n->num_shapes > 0 )
             {
-                for ( int s = n->offset; s < n->offset + n->num_shapes; ++s ) shape_intersect_band( d, (uint32_t)s, o, dir, hit, cnt, &ambiguous );
+                for ( int s = n->offset; s < n->offset + n->num_shapes; ++s ) shape_intersect_band( d, (uint32_t)s, o, dir, hit, cnt, &ambiguous, entry );
                 if ( top == 0 ) break;
                 node = stack[--top];
             }
@@ -403,6 +439,13 @@ static int bvh_intersect_ordered( const PtSceneDesc* d, v3 o, v3 dir, Hit* hit, 
             if ( top == 0 ) break;
             node = stack[--top];
         }
+    }
+    if ( ambiguous & 2 )
+    {
+        /* a hit that cannot be trusted: the reference's order from scratch */
+        *hit = start;
+        cnt->redone++;
+        return bvh_intersect( d, o, dir, hit, cnt );
     }
     if ( ambiguous )
     {
@@ -463,7 +506,7 @@ static int bvh_occluded_ordered( const PtSceneDesc* d, v3 o, v3 dir, float tMax,
 
 static int scene_intersect( const PtoScene* s, v3 o, v3 dir, Hit* hit, TravCount* cnt )
 {
-    return s->traversal == PT_TRAVERSAL_ORDERED ? bvh_intersect_ordered( &s->d, o, dir, hit, cnt ) : bvh_intersect( &s->d, o, dir, hit, cnt );
+    return s->traversal == PT_TRAVERSAL_ORDERED ? bvh_intersect_ordered( &s->d, s->sphere_below, o, dir, hit, cnt ) : bvh_intersect( &s->d, o, dir, hit, cnt );
 }
 
 static int scene_occluded_any( const PtoScene* s, v3 o, v3 dir, float tMax, TravCount* cnt )

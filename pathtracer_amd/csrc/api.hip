@@ -2,6 +2,7 @@
 // sequences the wavefront kernels, readback, batch ray queries.
 #include "pt_api.h"
 #include "pt_device.h"
+#include "wide_bvh.h"
 
 #include <algorithm>
 #include <chrono>
@@ -247,10 +248,12 @@ struct PtScene
     hipStream_t stream = nullptr;
     int gridBlocks = 2048;
     int extendBlocks = 1024, connectBlocks = 1024; // resident grids of the traversal kernels
+    int wideBlocks = 512, wideThreads = 1024, wideLdsStack = 8; // the wide closest-hit kernel: resident grid, block size, stack entries it keeps in LDS
     uint32_t topNodes = 0;                          // nodes at the front of the device array in breadth-first order
     bool directSum = false;                         // one light with one sample: ConnectKernel adds the direct light, no ResolveKernel
 
     // scene
+    DeviceBuffer wideNodes, widePrims, wideSpill;
     DeviceBuffer nodes, orderedNodes, shadowNodes, shadowTopWords, prims, triShade, spheres, materials, textures, texels, lights, skybox;
     SceneView view{};
     PtCamera camera{};
@@ -440,6 +443,22 @@ int Upload( PtScene* s, const PtSceneDesc* d, const std::vector< uint32_t >& esc
         s->topNodes = static_cast< uint32_t >( bfs.size() );
     }
 
+    // which subtrees hold a sphere (the front-to-back layouts enter their boxes whatever has been found, see kernels.hip);
+    // children lie behind their parent in the reference's pre-order, so one backward pass does it
+    std::vector< uint8_t > sphereBelow;
+    if ( d->num_spheres > 0 )
+    {
+        sphereBelow.assign( N, 0 );
+        for ( uint32_t i = N; i-- > 0; )
+        {
+            const PtBvhNode& n = d->nodes[i];
+            if ( n.num_shapes > 0 )
+                for ( uint32_t k = 0; k < n.num_shapes; ++k ) sphereBelow[i] |= d->prims[static_cast< uint64_t >( n.offset ) + k].type == PT_PRIM_SPHERE;
+            else
+                sphereBelow[i] = sphereBelow[i + 1] | sphereBelow[static_cast< uint32_t >( n.offset )];
+        }
+    }
+
     std::unique_ptr< float[] > nodes( new float[8ull * N] ); // every word is written below
     ParallelFor( N, [&]( uint64_t begin, uint64_t end ) {
         for ( uint64_t i = begin; i < end; ++i )
@@ -517,13 +536,13 @@ int Upload( PtScene* s, const PtSceneDesc* d, const std::vector< uint32_t >& esc
             if ( n.num_shapes > 0 )
             {
                 r[6] = static_cast< uint32_t >( n.offset ) | ( static_cast< uint32_t >( n.num_shapes - 1 ) << 28 );
-                r[7] = kLeafFlag;
+                r[7] = kLeafFlag | ( !sphereBelow.empty() && sphereBelow[i] ? kSphereBelowFlag : 0u );
                 return;
             }
             const uint32_t a = i + 1, b = static_cast< uint32_t >( n.offset );
             const uint32_t axis = n.axis < 3 ? n.axis : 0; // any choice of the near child gives the same hits
             r[6] = at[a];
-            r[7] = 2u + axis;
+            r[7] = ( 2u + axis ) | ( !sphereBelow.empty() && sphereBelow[i] ? kSphereBelowFlag : 0u );
             uint32_t* ra = &rec[16ull * at[a]];
             uint32_t* rb = &rec[16ull * at[b]];
             for ( uint32_t o = 0; o < 8; ++o )
@@ -807,8 +826,38 @@ int Upload( PtScene* s, const PtSceneDesc* d, const std::vector< uint32_t >& esc
     } );
     HIP_TRY( s->prims.Upload( prims.get(), 64ull * P ) );
     HIP_TRY( s->triShade.Upload( shade.get(), 128ull * P ) );
-    prims.reset();
     shade.reset();
+
+    // Fourth layout (wide_bvh.h): the tree collapsed to eight children per node, and the primitive records once more
+    // in that tree's order with the reference's index in place of the tag.  A tree it cannot express (a bound that is
+    // not finite, a box outside its parent's) simply has none.
+    uint32_t numWide = 0, wideDepth = 0;
+    if ( !( d->flags & PT_SCENE_NO_WIDE_LAYOUT ) )
+    {
+        WideLayout wide;
+        if ( BuildWideLayout( d, escape, sphereBelow.empty() ? nullptr : sphereBelow.data(), wide ) )
+        {
+            numWide   = static_cast< uint32_t >( wide.nodes.size() / kWideNodeWords );
+            wideDepth = wide.depth;
+            HIP_TRY( s->wideNodes.Upload( wide.nodes.data(), wide.nodes.size() * 4 ) );
+            std::vector< uint32_t >().swap( wide.nodes );
+            std::unique_ptr< float[] > ordered( new float[16ull * P] );
+            ParallelFor( P, [&]( uint64_t begin, uint64_t end ) {
+                for ( uint64_t k = begin; k < end; ++k )
+                {
+                    const uint32_t i = wide.primOrder[k];
+                    float* q = &ordered[16 * k];
+                    std::memcpy( q, &prims[16ull * i], 64 );
+                    const uint32_t tag = i | ( d->prims[i].type == PT_PRIM_SPHERE ? 0x80000000u : 0u );
+                    std::memcpy( &q[3], &tag, 4 );
+                }
+            } );
+            HIP_TRY( s->widePrims.Upload( ordered.get(), 64ull * P ) );
+            if ( wideDepth > static_cast< uint32_t >( s->wideLdsStack ) )
+                HIP_TRY( s->wideSpill.Allocate( 8ull * ( wideDepth - s->wideLdsStack ) * static_cast< uint64_t >( s->wideBlocks ) * s->wideThreads ) );
+        }
+    }
+    prims.reset();
 
     std::vector< float > spheres( 24ull * d->num_spheres, 0.0f );
     for ( uint64_t i = 0; i < d->num_spheres; ++i )
@@ -898,6 +947,10 @@ int Upload( PtScene* s, const PtSceneDesc* d, const std::vector< uint32_t >& esc
     v.numShadowTop  = shadowTop;
     v.numOrderedNodes = numOrdered;
     v.numTopOrdered = topOrdered;
+    v.wideNodes     = s->wideNodes.As< float4 >();
+    v.widePrims     = s->widePrims.As< float4 >();
+    v.numWideNodes  = numWide;
+    v.wideDepth     = wideDepth;
     v.prims         = s->prims.As< float4 >();
     v.triShade      = s->triShade.As< float4 >();
     v.spheres       = s->spheres.As< float4 >();
@@ -964,7 +1017,7 @@ int EnsurePathBuffers( PtScene* s, uint64_t capacity )
     HIP_TRY( s->shadowPaths.Allocate( entries * 4 ) );
     HIP_TRY( s->shadowRays.Allocate( entries * slots * 4 ) );
     if ( s->view.numSpheres ) HIP_TRY( s->sphereQueue.Allocate( entries * 4 ) );
-    if ( s->orderedNodes.ptr ) HIP_TRY( s->redo.Allocate( entries * 4 ) );
+    if ( s->orderedNodes.ptr || s->wideNodes.ptr ) HIP_TRY( s->redo.Allocate( entries * 4 ) );
     PathBuffers& p = s->paths;
     p.rayO[0]     = s->rayO0.As< float4 >();
     p.rayO[1]     = s->rayO1.As< float4 >();
@@ -1074,6 +1127,9 @@ try
         const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         s->extendBlocks  = extendPerCu * cus;
         s->connectBlocks = connectPerCu * cus;
+        int widePerCu = 1;
+        WideOccupancy( desc->num_spheres > 0, &widePerCu, &s->wideThreads, &s->wideLdsStack );
+        s->wideBlocks = widePerCu * cus;
     }
     hipError_t e = hipStreamCreate( &s->stream );
     if ( e != hipSuccess ) return Fail( PT_ERR_DEVICE, "hipStreamCreate failed: %s", hipGetErrorString( e ) );
@@ -1194,9 +1250,14 @@ try
     }
 
     const CameraFrame cam = MakeCameraFrame( s->camera, s->width, s->height );
-    const bool ordered = ( p->flags & PT_RENDER_ORDERED ) != 0;
-    if ( ordered && !s->orderedNodes.ptr ) return Fail( PT_ERR_STATE, "pt_render: PT_RENDER_ORDERED, but the scene was uploaded with PT_SCENE_NO_ORDERED_LAYOUT" );
-    const LaunchCfg cfg{ stream, s->gridBlocks, s->extendBlocks, s->connectBlocks, ordered };
+    const bool wide    = ( p->flags & PT_RENDER_WIDE ) != 0;
+    const bool ordered = ( p->flags & PT_RENDER_ORDERED ) != 0 || wide;
+    if ( wide && !s->wideNodes.ptr ) return Fail( PT_ERR_STATE, "pt_render: PT_RENDER_WIDE, but the scene has no wide layout (PT_SCENE_NO_WIDE_LAYOUT, or a tree it cannot express)" );
+    if ( ordered && !wide && !s->orderedNodes.ptr ) return Fail( PT_ERR_STATE, "pt_render: PT_RENDER_ORDERED, but the scene was uploaded with PT_SCENE_NO_ORDERED_LAYOUT" );
+    LaunchCfg cfg{ stream, s->gridBlocks, s->extendBlocks, s->connectBlocks, ordered };
+    cfg.wide       = wide;
+    cfg.wideBlocks = s->wideBlocks;
+    cfg.wideSpill  = s->wideSpill.As< uint2 >();
     SpanTimer timer{ s, stream, ( p->flags & PT_RENDER_PROFILE ) != 0 };
     uint64_t* stats = s->stats.As< uint64_t >();
     PathBuffers pb = s->paths;
@@ -1407,8 +1468,9 @@ int pt_trace_closest_mode( PtScene* s, uint32_t traversal, uint64_t n, const flo
 try
 {
     if ( !s || ( n && ( !origins || !directions ) ) ) return Fail( PT_ERR_INVALID_ARG, "pt_trace_closest: null argument" );
-    if ( traversal > PT_TRAVERSAL_ORDERED ) return Fail( PT_ERR_INVALID_ARG, "pt_trace_closest: unknown traversal order %u", traversal );
+    if ( traversal > PT_TRAVERSAL_WIDE ) return Fail( PT_ERR_INVALID_ARG, "pt_trace_closest: unknown traversal order %u", traversal );
     if ( traversal == PT_TRAVERSAL_ORDERED && !s->orderedNodes.ptr ) return Fail( PT_ERR_STATE, "pt_trace_closest: PT_TRAVERSAL_ORDERED, but the scene was uploaded with PT_SCENE_NO_ORDERED_LAYOUT" );
+    if ( traversal == PT_TRAVERSAL_WIDE && !s->wideNodes.ptr ) return Fail( PT_ERR_STATE, "pt_trace_closest: PT_TRAVERSAL_WIDE, but the scene has no wide layout" );
     if ( n == 0 ) return PT_OK;
     HIP_TRY( hipSetDevice( s->device ) );
     DeviceBuffer dO, dD, dPrim, dT, dU, dV, dN, dP;
@@ -1420,7 +1482,8 @@ try
     HIP_TRY( dV.Allocate( n * 4 ) );
     HIP_TRY( dN.Allocate( n * 4 ) );
     HIP_TRY( dP.Allocate( n * 4 ) );
-    const LaunchCfg cfg{ s->stream, s->gridBlocks, s->extendBlocks, s->connectBlocks, traversal == PT_TRAVERSAL_ORDERED };
+    LaunchCfg cfg{ s->stream, s->gridBlocks, s->extendBlocks, s->connectBlocks, traversal == PT_TRAVERSAL_ORDERED };
+    cfg.wide = traversal == PT_TRAVERSAL_WIDE;
     LaunchTraceClosest( cfg, s->view, n, dO.As< float >(), dD.As< float >(), dPrim.As< int32_t >(), dT.As< float >(), dU.As< float >(),
                         dV.As< float >(), dN.As< uint32_t >(), dP.As< uint32_t >() );
     HIP_TRY( hipGetLastError() );
@@ -1488,8 +1551,9 @@ int pt_trace_any_mode( PtScene* s, uint32_t traversal, uint64_t n, const float* 
 try
 {
     if ( !s || ( n && ( !origins || !directions || !t_max || !occluded ) ) ) return Fail( PT_ERR_INVALID_ARG, "pt_trace_any: null argument" );
-    if ( traversal > PT_TRAVERSAL_ORDERED ) return Fail( PT_ERR_INVALID_ARG, "pt_trace_any: unknown traversal order %u", traversal );
+    if ( traversal > PT_TRAVERSAL_WIDE ) return Fail( PT_ERR_INVALID_ARG, "pt_trace_any: unknown traversal order %u", traversal );
     if ( traversal == PT_TRAVERSAL_ORDERED && !s->orderedNodes.ptr ) return Fail( PT_ERR_STATE, "pt_trace_any: PT_TRAVERSAL_ORDERED, but the scene was uploaded with PT_SCENE_NO_ORDERED_LAYOUT" );
+    if ( traversal == PT_TRAVERSAL_WIDE && !s->wideNodes.ptr ) return Fail( PT_ERR_STATE, "pt_trace_any: PT_TRAVERSAL_WIDE, but the scene has no wide layout" );
     if ( n == 0 ) return PT_OK;
     HIP_TRY( hipSetDevice( s->device ) );
     DeviceBuffer dO, dD, dT, dOcc, dN, dP;
@@ -1499,7 +1563,8 @@ try
     HIP_TRY( dOcc.Allocate( n ) );
     HIP_TRY( dN.Allocate( n * 4 ) );
     HIP_TRY( dP.Allocate( n * 4 ) );
-    const LaunchCfg cfg{ s->stream, s->gridBlocks, s->extendBlocks, s->connectBlocks, traversal == PT_TRAVERSAL_ORDERED };
+    LaunchCfg cfg{ s->stream, s->gridBlocks, s->extendBlocks, s->connectBlocks, traversal == PT_TRAVERSAL_ORDERED };
+    cfg.wide = traversal == PT_TRAVERSAL_WIDE;
     LaunchTraceAny( cfg, s->view, n, dO.As< float >(), dD.As< float >(), dT.As< float >(), dOcc.As< uint8_t >(), dN.As< uint32_t >(), dP.As< uint32_t >() );
     HIP_TRY( hipGetLastError() );
     HIP_TRY( hipStreamSynchronize( s->stream ) );

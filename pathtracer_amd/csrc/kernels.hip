@@ -178,8 +178,9 @@ typedef float f2 __attribute__( ( ext_vector_type( 2 ) ) );
 // in adjacent registers, which is what the packed two-float subtract / multiply of the slab arithmetic wants.
 // kInclusive: the box is entered when tMin <= maxT instead of tMin < maxT - the front-to-back closest-hit traversal
 // needs it, because a primitive at exactly the distance of the closest hit so far may still win by its lower index.
+// *entry: the distance at which the ray enters the box (the reference's tMin after the three slabs)
 template < bool kInclusive = false >
-__device__ __forceinline__ bool RayBox( f3 o, f3 inv, bool nx, bool ny, bool nz, float4 a, float4 b, float maxT )
+__device__ __forceinline__ bool RayBoxEntry( f3 o, f3 inv, bool nx, bool ny, bool nz, float4 a, float4 b, float maxT, float* entry )
 {
     // Both early returns of the reference are folded into flags: once one of them would have fired the later
     // values are never looked at, so evaluating everything up front gives the same answer and lets the whole
@@ -196,7 +197,15 @@ __device__ __forceinline__ bool RayBox( f3 o, f3 inv, bool nx, bool ny, bool nz,
     const bool missZ = ( tMin > tzMax ) | ( tzMin > tMax );
     if ( tzMin > tMin ) tMin = tzMin;
     if ( tzMax < tMax ) tMax = tzMax;
+    *entry = tMin;
     return !missXY & !missZ & ( kInclusive ? tMin <= maxT : tMin < maxT ) & ( tMax > 0 );
+}
+
+template < bool kInclusive = false >
+__device__ __forceinline__ bool RayBox( f3 o, f3 inv, bool nx, bool ny, bool nz, float4 a, float4 b, float maxT )
+{
+    float entry;
+    return RayBoxEntry< kInclusive >( o, inv, nx, ny, nz, a, b, maxT, &entry );
 }
 
 struct HitRecord
@@ -212,8 +221,22 @@ struct HitRecord
 // distance so far, and `ambiguous` records whether a second hit lies within that band of the closest one.
 constexpr float kBand = 1.0f + 1.0f / 4096.0f;
 
+// kTrust: a hit of the front-to-back modes whose distance lies this far in front of the point where the ray enters the
+// primitive's own leaf box comes from a primitive test that has lost its precision (a sphere seen from ten thousand radii
+// away, a triangle met at a millionth of a degree).  The band argument rests on a hit lying inside its boxes, so such a ray
+// is traced in the reference's order from scratch (bit 1 of `ambiguous`; bit 0: a second hit within the band).
+constexpr float kTrust = 1.0f + 1.0f / 16384.0f;
+constexpr uint32_t kAmbiguous = 1u, kUntrusted = 2u;
+
+struct RaySide // what the reference's box test derives from a direction (bvh.cpp:235-236)
+{
+    f3 inv;
+    bool nx, ny, nz;
+};
+
 template < bool kSpheres = true, bool kOrdered = false >
-__device__ __forceinline__ void ClosestPrimTest( const SceneView& sv, const SceneBuffers& sb, uint32_t prim, f3 o, f3 d, HitRecord& h, bool* wasSphere, bool* ambiguous = nullptr )
+__device__ __forceinline__ void ClosestPrimTest( const SceneView& sv, const SceneBuffers& sb, uint32_t prim, f3 o, f3 d, HitRecord& h, bool* wasSphere, uint32_t* ambiguous = nullptr,
+                                                 const RaySide* side = nullptr )
 {
     float4 q0 = Load16( sb.prims, 64u * prim );
     const float4 q1 = Load16( sb.prims, 64u * prim + 16u ), q2 = Load16( sb.prims, 64u * prim + 32u );
@@ -236,13 +259,19 @@ __device__ __forceinline__ void ClosestPrimTest( const SceneView& sv, const Scen
     }
     if constexpr ( kOrdered )
     {
+        // where the ray enters the box of the primitive's leaf (the box travels in the record)
+        const float4 q3 = Load16( sb.prims, 64u * prim + 48u );
+        float entry;
+        RayBoxEntry< true >( o, side->inv, side->nx, side->ny, side->nz, make_float4( q1.w, q2.w, q3.y, q3.z ), make_float4( q3.x, q3.w, 0.0f, 0.0f ), limit, &entry );
+        if ( hit && entry > t * kTrust ) *ambiguous |= kUntrusted;
         if ( hit && t < h.t )
         {
-            *ambiguous = h.t <= t * kBand; // the hit it replaces was within the band of the new one (else everything so far lies beyond it)
+            // the hit it replaces was within the band of the new one (else everything so far lies beyond it)
+            *ambiguous = ( *ambiguous & kUntrusted ) | ( h.t <= t * kBand ? kAmbiguous : 0u );
             h          = HitRecord{ t, u, v, static_cast< int >( prim ) };
         }
         else if ( hit )
-            *ambiguous = true;
+            *ambiguous |= kAmbiguous;
     }
     else if ( hit )
         h = HitRecord{ t, u, v, static_cast< int >( prim ) };
@@ -334,6 +363,7 @@ __device__ __forceinline__ bool TraceAny( const SceneView& sv, const SceneBuffer
 // pass find nothing below its start (it cannot, the closest hit of the first pass lies there), it runs unbounded.
 __device__ __forceinline__ HitRecord RetraceInReferenceOrder( const SceneView& sv, const SceneBuffers& sb, f3 o, f3 d, float closest, Counters& cnt )
 {
+    if ( closest == FLT_MAX ) return TraceClosest( sv, sb, o, d, cnt ); // nothing to start from (an untrusted hit): the reference's pass as it is
     const float start = ( closest * kBand ) * kBand;
     HitRecord h = TraceClosest( sv, sb, o, d, cnt, start );
     if ( h.prim < 0 ) h = TraceClosest( sv, sb, o, d, cnt );
@@ -363,22 +393,26 @@ __device__ __forceinline__ HitRecord RetraceInReferenceOrder( const SceneView& s
 __device__ __forceinline__ uint32_t LinkOffset( bool nx, bool ny, bool nz ) { return 32u + 4u * ( ( nx ? 1u : 0u ) | ( ny ? 2u : 0u ) | ( nz ? 4u : 0u ) ); }
 __device__ __forceinline__ uint32_t NearChild( uint32_t w0, uint32_t w1, uint32_t linkOffset ) { return w0 + ( ( linkOffset >> ( w1 & 7u ) ) & 1u ); }
 
-__device__ __forceinline__ HitRecord TraceClosestOrdered( const SceneView& sv, const SceneBuffers& sb, f3 o, f3 d, Counters& cnt, bool* ambiguous )
+__device__ __forceinline__ HitRecord TraceClosestOrdered( const SceneView& sv, const SceneBuffers& sb, f3 o, f3 d, Counters& cnt, uint32_t* ambiguous )
 {
     HitRecord h{ FLT_MAX, 0.0f, 0.0f, -1 };
     const f3 inv  = F3( 1.0f / d.x, 1.0f / d.y, 1.0f / d.z );
     const bool nx = inv.x < 0, ny = inv.y < 0, nz = inv.z < 0;
     const uint32_t linkOffset = LinkOffset( nx, ny, nz );
     const uint32_t end = sv.numOrderedNodes;
+    const RaySide side{ inv, nx, ny, nz };
     uint32_t node = 0;
-    *ambiguous = false;
+    *ambiguous = 0u;
     while ( node != end )
     {
         const float4 a = Load16( sb.nodes, 64u * node ), b = Load16( sb.nodes, 64u * node + 16u );
         const uint32_t link = Load4( sb.nodes, 64u * node + linkOffset );
         cnt.nodes++;
         const uint32_t w0 = __float_as_uint( b.z ), w1 = __float_as_uint( b.w );
-        const bool boxHit = RayBox< true >( o, inv, nx, ny, nz, a, b, h.t * kBand );
+        // a box with a sphere inside is entered whatever has been found: the sphere test, which runs in the sphere's own
+        // space, loses its precision with the distance of the origin long before the box test does, and a sphere hit that
+        // the reference computes in front of the sphere's box has to be seen here to be told apart (kUntrusted)
+        const bool boxHit = RayBox< true >( o, inv, nx, ny, nz, a, b, ( w1 & kSphereBelowFlag ) ? INFINITY : h.t * kBand );
         if ( boxHit && !( w1 & kLeafFlag ) )
         {
             node = NearChild( w0, w1, linkOffset );
@@ -390,7 +424,7 @@ __device__ __forceinline__ HitRecord TraceClosestOrdered( const SceneView& sv, c
         for ( uint32_t k = 0; k < count; ++k )
         {
             bool wasSphere;
-            ClosestPrimTest< true, true >( sv, sb, first + k, o, d, h, &wasSphere, ambiguous );
+            ClosestPrimTest< true, true >( sv, sb, first + k, o, d, h, &wasSphere, ambiguous, &side );
             cnt.tris += wasSphere ? 0 : 1;
             cnt.spheres += wasSphere ? 1 : 0;
         }
@@ -426,6 +460,265 @@ __device__ __forceinline__ bool TraceAnyOrdered( const SceneView& sv, const Scen
         {
             bool wasSphere;
             const bool hit = AnyPrimTest( sb, first + k, o, d, tMax, &wasSphere );
+            cnt.tris += wasSphere ? 0 : 1;
+            cnt.spheres += wasSphere ? 1 : 0;
+            if ( hit ) return true;
+        }
+    }
+    return false;
+}
+
+// ---- wide nodes ---------------------------------------------------------------------------------------------
+//
+// Fourth layout (wide_bvh.h): the reference's tree collapsed into nodes of up to eight children, the child boxes as
+// bytes on a grid over the node's own box, rounded outwards.  One node visit is five 16-byte loads and eight box
+// tests, where the binary layouts spend two or three loads on one; a ray makes a fifth of the visits.  The traversal
+// keeps a short stack per ray: what is left of a node's hit children (the index of the node's first inner child, the
+// mask of its inner slots, the mask of the hit ones).
+// What keeps the answers the reference's.  The quantised boxes are outer bounds of the reference's boxes, and the
+// test below is an outer bound of the reference's test: a child is skipped only if the reference's own slab test
+// (src/intersection_tests.cpp:91-110) of the child's box - and with it of every box inside - would fail.  So the
+// traversal reaches every primitive the front-to-back traversal of the exact boxes (TraceClosestOrdered) reaches, and
+// possibly more; a primitive then counts only if the reference's test of its leaf's box, carried in its record,
+// passes - exactly the condition under which the exact-box traversal would have tested it.  From there on the rules
+// of the front-to-back mode apply unchanged: hits within kBand of the closest are kept alive, a ray that saw two is
+// traced again in the reference's order.
+//
+// The box test.  Along one axis a child plane is X = p + q * cell (exact, as a real number), and the reference would
+// compute t = fl( fl( L - o ) * inv ) for a plane L of the exact box, L >= X for a low plane.  Here t~ = fma( q, A, B )
+// with A = cell * inv (exact: cell is a power of two) and B = fl( fl( p - o ) * inv ).  With u = 2^-24:
+//   |t~ - ( X - o ) inv| <= 2.02 u |B| + 1.01 u |t~|,   |t - ( L - o ) inv| <= 2.01 u ( 1.01 |B| + 255 |A| ),
+//   |t~| <= ( |B| + 255 |A| )( 1 + u ),
+// so t >= t~ - E for a near plane and t <= t~ + E for a far plane with E = 2^-21 ( |B| + 255 |A| ) (6.1 u would do).
+// The reference passes a box only if max( near ) <= min( far ), max( near ) <= limit and min( far ) > 0; the test
+// below passes whenever max( near~ ) - E <= min( far~ ) + E, max( near~ ) - E <= limit and min( far~ ) + E >= 0, E the
+// largest of the three axes'.  Anything that is not a number passes (comparisons are written so that a NaN enters).
+// A direction component of zero makes inv infinite, and the reference's slab test on that axis a containment test
+// of the origin, whatever the magnitude of inv: the wide test uses 2^100 in its place, which keeps the arithmetic
+// finite.  A ray with a finite reciprocal beyond 2^100 (a direction component below 2^-100) is not traversed here at
+// all: it is handed to the pass in the reference's order like an ambiguous one.
+constexpr uint32_t kWideNodeBytes = 80u;
+constexpr float kWideInvLimit = 1.2676506002282294e30f; // 2^100
+constexpr float kWideSlack = 1.0f / 2097152.0f;          // 2^-21
+constexpr uint32_t kWideStackEntries = 56;                // kWideMaxDepth of wide_bvh.h
+
+__device__ __forceinline__ bool WideDegenerate( f3 inv )
+{
+    const float ax = fabsf( inv.x ), ay = fabsf( inv.y ), az = fabsf( inv.z );
+    return ( ax > kWideInvLimit && ax < INFINITY ) || ( ay > kWideInvLimit && ay < INFINITY ) || ( az > kWideInvLimit && az < INFINITY );
+}
+
+// Per axis the slots a ray prefers - those on the side it comes from -, z in the low byte, then y, then x
+__device__ __forceinline__ uint32_t WideOctMasks( bool nx, bool ny, bool nz )
+{
+    return ( nz ? 0xF0u : 0x0Fu ) | ( ny ? 0xCC00u : 0x3300u ) | ( nx ? 0xAA0000u : 0x550000u );
+}
+
+// Of the slots in `hits` (not empty) the one with the smallest slot ^ octant: the nearest, as far as slots tell
+__device__ __forceinline__ uint32_t WidePick( uint32_t hits, uint32_t octMasks )
+{
+    uint32_t t = hits & octMasks;
+    hits = t ? t : hits;
+    t    = hits & ( octMasks >> 8 );
+    hits = t ? t : hits;
+    t    = hits & ( octMasks >> 16 );
+    hits = t ? t : hits;
+    return static_cast< uint32_t >( __builtin_ctz( hits ) );
+}
+
+__device__ __forceinline__ float WideByte( uint32_t w, int k ) { return static_cast< float >( ( w >> ( 8 * k ) ) & 0xFFu ); }
+
+// The eight box tests of one wide node: n0 = words 0..3 of its record, n2..n4 = the planes.  Bit s of the result: the
+// ray may enter the child in slot s (empty slots are the caller's to mask off).
+// kUnlimited: the high half of the result holds the same bits for limit = infinity.
+template < bool kUnlimited = false >
+__device__ __forceinline__ uint32_t WideBoxes( float4 n0, float4 n2, float4 n3, float4 n4, f3 o, f3 inv, bool nx, bool ny, bool nz, float limit )
+{
+    const uint32_t w3 = __float_as_uint( n0.w );
+    const float ix = __builtin_amdgcn_fmed3f( inv.x, -kWideInvLimit, kWideInvLimit ), iy = __builtin_amdgcn_fmed3f( inv.y, -kWideInvLimit, kWideInvLimit ),
+                iz = __builtin_amdgcn_fmed3f( inv.z, -kWideInvLimit, kWideInvLimit );
+    const float ax = __uint_as_float( ( w3 & 0xFFu ) << 23 ) * ix, ay = __uint_as_float( ( w3 & 0xFF00u ) << 15 ) * iy, az = __uint_as_float( ( w3 & 0xFF0000u ) << 7 ) * iz;
+    const float bx = ( n0.x - o.x ) * ix, by = ( n0.y - o.y ) * iy, bz = ( n0.z - o.z ) * iz;
+    const float e  = __builtin_fmaxf( __builtin_fmaxf( __builtin_fmaf( fabsf( ax ), 255.0f * kWideSlack, fabsf( bx ) * kWideSlack ),
+                                                       __builtin_fmaf( fabsf( ay ), 255.0f * kWideSlack, fabsf( by ) * kWideSlack ) ),
+                                      __builtin_fmaf( fabsf( az ), 255.0f * kWideSlack, fabsf( bz ) * kWideSlack ) );
+    const float e2 = e + e;
+    // near planes carry -2 E, so that max( near ) <= min( far ) below is the test with E on either side
+    const f2 ax2 = f2{ ax, ax }, ay2 = f2{ ay, ay }, az2 = f2{ az, az };
+    const f2 bx2 = f2{ bx - e2, bx }, by2 = f2{ by - e2, by }, bz2 = f2{ bz - e2, bz };
+    const float lower = -e, upper = limit - e;
+    const uint32_t lox[2] = { __float_as_uint( n2.x ), __float_as_uint( n2.y ) }, loy[2] = { __float_as_uint( n2.z ), __float_as_uint( n2.w ) },
+                   loz[2] = { __float_as_uint( n3.x ), __float_as_uint( n3.y ) }, hix[2] = { __float_as_uint( n3.z ), __float_as_uint( n3.w ) },
+                   hiy[2] = { __float_as_uint( n4.x ), __float_as_uint( n4.y ) }, hiz[2] = { __float_as_uint( n4.z ), __float_as_uint( n4.w ) };
+    uint32_t nearX[2], farX[2], nearY[2], farY[2], nearZ[2], farZ[2];
+#pragma unroll
+    for ( int k = 0; k < 2; ++k )
+    {
+        nearX[k] = nx ? hix[k] : lox[k]; farX[k] = nx ? lox[k] : hix[k];
+        nearY[k] = ny ? hiy[k] : loy[k]; farY[k] = ny ? loy[k] : hiy[k];
+        nearZ[k] = nz ? hiz[k] : loz[k]; farZ[k] = nz ? loz[k] : hiz[k];
+    }
+    uint32_t hits = 0;
+#pragma unroll
+    for ( int s = 0; s < 8; ++s )
+    {
+        const int w = s >> 2, k = s & 3;
+        const f2 tx = __builtin_elementwise_fma( f2{ WideByte( nearX[w], k ), WideByte( farX[w], k ) }, ax2, bx2 );
+        const f2 ty = __builtin_elementwise_fma( f2{ WideByte( nearY[w], k ), WideByte( farY[w], k ) }, ay2, by2 );
+        const f2 tz = __builtin_elementwise_fma( f2{ WideByte( nearZ[w], k ), WideByte( farZ[w], k ) }, az2, bz2 );
+        const float tMin = __builtin_fmaxf( __builtin_fmaxf( __builtin_fmaxf( tx.x, ty.x ), tz.x ), lower );
+        const float tFar = __builtin_fminf( __builtin_fminf( tx.y, ty.y ), tz.y );
+        const float tMax = __builtin_fminf( tFar, upper );
+        hits |= !( tMin > tMax ) ? 1u << s : 0u;
+        if constexpr ( kUnlimited ) hits |= !( tMin > tFar ) ? 0x10000u << s : 0u;
+    }
+    return hits;
+}
+
+// The state a traversal keeps of the node it tested last: what is left to visit of its children
+struct WideGroup
+{
+    uint32_t childBase, primBase;
+    uint32_t bits; // hit inner slots | inner slots << 8 | hit leaf slots << 16 | leaf slots << 24
+};
+
+// kSpheres (closest-hit traversals of a scene with spheres): a child with a sphere below it is entered whatever has been
+// found - see TraceClosestOrdered
+template < bool kSpheres = false >
+__device__ __forceinline__ WideGroup WideVisit( BufferDesc nodes, uint32_t node, f3 o, f3 inv, bool nx, bool ny, bool nz, float limit )
+{
+    const uint32_t at = kWideNodeBytes * node;
+    const float4 n0 = Load16( nodes, at ), n1 = Load16( nodes, at + 16u ), n2 = Load16( nodes, at + 32u ), n3 = Load16( nodes, at + 48u ), n4 = Load16( nodes, at + 64u );
+    uint32_t hits = WideBoxes< kSpheres >( n0, n2, n3, n4, o, inv, nx, ny, nz, limit );
+    if constexpr ( kSpheres ) hits = ( hits | ( ( hits >> 16 ) & __float_as_uint( n1.w ) ) ) & 0xFFu;
+    const uint32_t imask = __float_as_uint( n0.w ) >> 24, lmask = __float_as_uint( n1.z ) & 0xFFu;
+    return WideGroup{ __float_as_uint( n1.x ), __float_as_uint( n1.y ), ( hits & imask ) | imask << 8 | ( hits & lmask ) << 16 | lmask << 24 };
+}
+
+// Closest-hit test of the primitive in position `slot` of the wide primitive array (ClosestPrimTest< ., true > plus the
+// reference's test of the leaf box, see above)
+template < bool kSpheres >
+__device__ __forceinline__ void ClosestPrimTestWide( const SceneView& sv, BufferDesc prims, uint32_t slot, f3 o, f3 d, f3 inv, bool nx, bool ny, bool nz,
+                                                     HitRecord& h, bool* wasSphere, uint32_t* ambiguous )
+{
+    const float4 q0 = Load16( prims, 64u * slot ), q1 = Load16( prims, 64u * slot + 16u ), q2 = Load16( prims, 64u * slot + 32u ), q3 = Load16( prims, 64u * slot + 48u );
+    const uint32_t tag = __float_as_uint( q0.w ); // index in the reference's order, top bit: sphere
+    float t = 0.0f, u = 0.0f, v = 0.0f;
+    const float limit = h.t * kBand;
+    bool hit   = RayTriangle( o, d, F3( q0 ), F3( q1 ), F3( q2 ), limit, &t, &u, &v );
+    *wasSphere = kSpheres && ( tag & 0x80000000u ) != 0;
+    if ( *wasSphere )
+    {
+        const float4* s = sv.spheres + 6 * __float_as_uint( q1.y );
+        const float4 c0 = s[0], c1 = s[1], c2 = s[2], c3 = s[3];
+        f3 lo = MatMul( c0, c1, c2, c3, o, 1.0f );
+        f3 ld = MatMul( c0, c1, c2, c3, d, 0.0f );
+        u = v = 0.0f;
+        hit   = RaySphere( lo, ld, F3( 0.0f, 0.0f, 0.0f ), 1.0f, limit, &t );
+    }
+    // the reference reaches the primitive only through its leaf's box (bvh.cpp:242)
+    float entry;
+    hit = hit & RayBoxEntry< true >( o, inv, nx, ny, nz, make_float4( q1.w, q2.w, q3.y, q3.z ), make_float4( q3.x, q3.w, 0.0f, 0.0f ), *wasSphere ? INFINITY : limit, &entry );
+    if ( hit && entry > t * kTrust ) *ambiguous |= kUntrusted;
+    if ( hit && t < h.t )
+    {
+        *ambiguous = ( *ambiguous & kUntrusted ) | ( h.t <= t * kBand ? kAmbiguous : 0u );
+        h          = HitRecord{ t, u, v, static_cast< int >( tag & 0x7FFFFFFFu ) };
+    }
+    else if ( hit )
+        *ambiguous |= kAmbiguous;
+}
+
+__device__ __forceinline__ bool AnyPrimTestWide( BufferDesc prims, uint32_t slot, f3 o, f3 d, f3 inv, bool nx, bool ny, bool nz, float tMax, bool* wasSphere )
+{
+    const float4 q0 = Load16( prims, 64u * slot ), q1 = Load16( prims, 64u * slot + 16u ), q2 = Load16( prims, 64u * slot + 32u ), q3 = Load16( prims, 64u * slot + 48u );
+    float t = 0.0f, u, v;
+    bool hit   = RayTriangle( o, d, F3( q0 ), F3( q1 ), F3( q2 ), tMax, &t, &u, &v );
+    *wasSphere = ( __float_as_uint( q0.w ) & 0x80000000u ) != 0;
+    if ( *wasSphere ) hit = RaySphere( o, d, F3( q0 ), q1.x, tMax, &t );
+    return hit & RayBox( o, inv, nx, ny, nz, make_float4( q1.w, q2.w, q3.y, q3.z ), make_float4( q3.x, q3.w, 0.0f, 0.0f ), tMax );
+}
+
+__device__ __forceinline__ SceneBuffers MakeWideBuffers( const SceneView& sv )
+{
+    return SceneBuffers{ MakeBuffer( sv.wideNodes, sv.numWideNodes * kWideNodeBytes ), MakeBuffer( sv.widePrims, sv.numPrims * 64u ) };
+}
+
+// Closest hit over the wide layout, one ray per thread (the batch queries; the render path is ExtendWideKernel).
+// *ambiguous: the ray has to be traced again in the reference's order.
+__device__ __forceinline__ HitRecord TraceClosestWide( const SceneView& sv, const SceneBuffers& sb, f3 o, f3 d, Counters& cnt, uint32_t* ambiguous )
+{
+    HitRecord h{ FLT_MAX, 0.0f, 0.0f, -1 };
+    const f3 inv  = F3( 1.0f / d.x, 1.0f / d.y, 1.0f / d.z );
+    const bool nx = inv.x < 0, ny = inv.y < 0, nz = inv.z < 0;
+    *ambiguous    = WideDegenerate( inv ) ? kUntrusted : 0u;
+    if ( *ambiguous ) return h;
+    const uint32_t octMasks = WideOctMasks( nx, ny, nz );
+    uint2 stack[kWideStackEntries];
+    uint32_t sp = 0;
+    WideGroup g{ 0u, 0u, 0x0101u }; // the root as the one child of a node above it
+    for ( ;; )
+    {
+        uint32_t ih = g.bits & 0xFFu, im = ( g.bits >> 8 ) & 0xFFu, base = g.childBase;
+        if ( ih == 0 )
+        {
+            if ( sp == 0 ) break;
+            --sp;
+            base = stack[sp].x;
+            ih   = stack[sp].y & 0xFFu;
+            im   = stack[sp].y >> 8;
+        }
+        const uint32_t s = WidePick( ih, octMasks );
+        ih &= ~( 1u << s );
+        if ( ih && sp < kWideStackEntries ) stack[sp++] = make_uint2( base, im << 8 | ih );
+        g = WideVisit< true >( sb.nodes, base + __popc( im & ( ( 1u << s ) - 1u ) ), o, inv, nx, ny, nz, h.t * kBand );
+        cnt.nodes++;
+        const uint32_t lmask = g.bits >> 24;
+        for ( uint32_t l = ( g.bits >> 16 ) & 0xFFu; l; l &= l - 1u )
+        {
+            const uint32_t k = static_cast< uint32_t >( __builtin_ctz( l ) );
+            bool wasSphere;
+            ClosestPrimTestWide< true >( sv, sb.prims, g.primBase + __popc( lmask & ( ( 1u << k ) - 1u ) ), o, d, inv, nx, ny, nz, h, &wasSphere, ambiguous );
+            cnt.tris += wasSphere ? 0 : 1;
+            cnt.spheres += wasSphere ? 1 : 0;
+        }
+    }
+    return h;
+}
+
+// Any hit over the wide layout: the reference's answer in any order, since a primitive counts only if the reference's
+// test of its leaf box against the fixed tMax passes
+__device__ __forceinline__ bool TraceAnyWide( const SceneView& sv, const SceneBuffers& sb, f3 o, f3 d, float tMax, Counters& cnt )
+{
+    const f3 inv  = F3( 1.0f / d.x, 1.0f / d.y, 1.0f / d.z );
+    const bool nx = inv.x < 0, ny = inv.y < 0, nz = inv.z < 0;
+    if ( WideDegenerate( inv ) ) return TraceAny( sv, MakeSceneBuffers< false >( sv ), o, d, tMax, cnt );
+    const uint32_t octMasks = WideOctMasks( nx, ny, nz );
+    uint2 stack[kWideStackEntries];
+    uint32_t sp = 0;
+    WideGroup g{ 0u, 0u, 0x0101u };
+    for ( ;; )
+    {
+        uint32_t ih = g.bits & 0xFFu, im = ( g.bits >> 8 ) & 0xFFu, base = g.childBase;
+        if ( ih == 0 )
+        {
+            if ( sp == 0 ) break;
+            --sp;
+            base = stack[sp].x;
+            ih   = stack[sp].y & 0xFFu;
+            im   = stack[sp].y >> 8;
+        }
+        const uint32_t s = WidePick( ih, octMasks );
+        ih &= ~( 1u << s );
+        if ( ih && sp < kWideStackEntries ) stack[sp++] = make_uint2( base, im << 8 | ih );
+        g = WideVisit( sb.nodes, base + __popc( im & ( ( 1u << s ) - 1u ) ), o, inv, nx, ny, nz, tMax );
+        cnt.nodes++;
+        const uint32_t lmask = g.bits >> 24;
+        for ( uint32_t l = ( g.bits >> 16 ) & 0xFFu; l; l &= l - 1u )
+        {
+            const uint32_t k = static_cast< uint32_t >( __builtin_ctz( l ) );
+            bool wasSphere;
+            const bool hit = AnyPrimTestWide( sb.prims, g.primBase + __popc( lmask & ( ( 1u << k ) - 1u ) ), o, d, inv, nx, ny, nz, tMax, &wasSphere );
             cnt.tris += wasSphere ? 0 : 1;
             cnt.spheres += wasSphere ? 1 : 0;
             if ( hit ) return true;
@@ -828,7 +1121,7 @@ __global__ __launch_bounds__( kSpheres ? kTraverseBlock : kTriangleBlock ) __att
     f3 o = F3( 0.0f, 0.0f, 0.0f ), d = o, inv = o;
     bool nx = false, ny = false, nz = false;
     uint32_t linkOffset = 32u; // kOrdered: byte offset of the ray's link in a node record
-    bool ambiguous = false;    // kOrdered: a second hit within kBand of the closest one, see TraceClosestOrdered
+    uint32_t ambiguous = 0;    // kOrdered: kAmbiguous (a second hit within kBand of the closest one, see TraceClosestOrdered) | kUntrusted
     HitRecord h{ FLT_MAX, 0.0f, 0.0f, -1 };
     uint32_t waveRays = 0, waveNodes = 0, waveTris = 0, waveSpheres = 0, waveSteps = 0; // whole-wave totals, wave-uniform
 
@@ -844,7 +1137,8 @@ __global__ __launch_bounds__( kSpheres ? kTraverseBlock : kTriangleBlock ) __att
 
         if ( mRay && ( __popcll( mRay ) >= kExtendRefillLanes || ( mTrav | mLeaf ) == 0 ) )
         {
-            if ( idle && entry != kNoRay ) pb.hit[entry] = make_float4( h.t, h.u, h.v, __int_as_float( h.prim ) );
+            // (an untrusted hit leaves no distance for the second pass to start from)
+            if ( idle && entry != kNoRay ) pb.hit[entry] = make_float4( kOrdered && ( ambiguous & kUntrusted ) ? FLT_MAX : h.t, h.u, h.v, __int_as_float( h.prim ) );
             if constexpr ( kOrdered )
             {
                 // ambiguous rays are traced again in the reference's order by RedoKernel (rare: one atomic each)
@@ -871,7 +1165,7 @@ __global__ __launch_bounds__( kSpheres ? kTraverseBlock : kTriangleBlock ) __att
                     nx = inv.x < 0; ny = inv.y < 0; nz = inv.z < 0;
                     if constexpr ( kOrdered ) linkOffset = LinkOffset( nx, ny, nz );
                     h    = HitRecord{ FLT_MAX, 0.0f, 0.0f, -1 };     // scene.cpp:372
-                    ambiguous = false;
+                    ambiguous = 0u;
                     node = 0;
                 }
                 const uint32_t given = asking < left ? asking : left;
@@ -889,7 +1183,8 @@ __global__ __launch_bounds__( kSpheres ? kTraverseBlock : kTriangleBlock ) __att
                 bool isTri = false, isSphere = false;
                 if ( k < shapes )
                 {
-                    ClosestPrimTest< kSpheres, kOrdered >( sv, sb, first + k, o, d, h, &isSphere, &ambiguous );
+                    const RaySide side{ inv, nx, ny, nz };
+                    ClosestPrimTest< kSpheres, kOrdered >( sv, sb, first + k, o, d, h, &isSphere, &ambiguous, &side );
                     isTri = !isSphere;
                 }
                 waveTris += LanesSet( isTri );
@@ -929,7 +1224,7 @@ __global__ __launch_bounds__( kSpheres ? kTraverseBlock : kTriangleBlock ) __att
                         link = Load4( sb.nodes, 64u * node + linkOffset );
                     }
                     const uint32_t w0 = __float_as_uint( b.z ), w1 = __float_as_uint( b.w );
-                    const bool boxHit = RayBox< true >( o, inv, nx, ny, nz, a, b, h.t * kBand );
+                    const bool boxHit = RayBox< true >( o, inv, nx, ny, nz, a, b, ( kSpheres && ( w1 & kSphereBelowFlag ) ) ? INFINITY : h.t * kBand );
                     if ( boxHit && !( w1 & kLeafFlag ) )
                         node = NearChild( w0, w1, linkOffset );
                     else
@@ -990,6 +1285,177 @@ __global__ __launch_bounds__( kBlock ) void RedoKernel( SceneView sv, PathBuffer
     FlushCounter( stats, ST_NODES_CLOSEST, cnt.nodes );
     FlushCounter( stats, ST_TRI_CLOSEST, cnt.tris );
     FlushCounter( stats, ST_SPH_CLOSEST, cnt.spheres );
+}
+
+// ExtendKernel over the wide layout (see "wide nodes" above): the same wave-level scheduling - refill, leaf phase,
+// bursts of node visits - with a short stack per lane.  The first kWideLdsStack entries of a lane's stack live in LDS
+// (entry-major, so that the lanes of a wave touch consecutive words), deeper ones in `spill`, one slot per thread of
+// the grid and level; the tree's depth bounds the stack, because a level pushes at most one entry.  Results and the
+// queue of rays to trace again are ExtendKernel< ., true >'s.
+#ifndef PT_WIDE_BLOCK
+#define PT_WIDE_BLOCK 1024
+#endif
+#ifndef PT_WIDE_WAVES
+#define PT_WIDE_WAVES 8
+#endif
+#ifndef PT_WIDE_SPHERE_BLOCK
+#define PT_WIDE_SPHERE_BLOCK 768
+#endif
+#ifndef PT_WIDE_SPHERE_WAVES
+#define PT_WIDE_SPHERE_WAVES 6
+#endif
+#ifndef PT_WIDE_LDS_STACK
+#define PT_WIDE_LDS_STACK 8
+#endif
+#ifndef PT_WIDE_REFILL_LANES
+#define PT_WIDE_REFILL_LANES 24
+#endif
+#ifndef PT_WIDE_LEAF_LANES
+#define PT_WIDE_LEAF_LANES 12
+#endif
+#ifndef PT_WIDE_BURST
+#define PT_WIDE_BURST 2
+#endif
+constexpr int kWideBlock = PT_WIDE_BLOCK, kWideSphereBlock = PT_WIDE_SPHERE_BLOCK;
+constexpr uint32_t kWideLdsStack = PT_WIDE_LDS_STACK;
+
+template < bool kSpheres >
+__global__ __launch_bounds__( kSpheres ? kWideSphereBlock : kWideBlock ) __attribute__( ( amdgpu_waves_per_eu( kSpheres ? PT_WIDE_SPHERE_WAVES : PT_WIDE_WAVES, kSpheres ? PT_WIDE_SPHERE_WAVES : PT_WIDE_WAVES ) ) )
+void ExtendWideKernel( SceneView sv, PathBuffers pb, int bounce, uint32_t numPaths, uint2* spill, uint64_t* stats )
+{
+    constexpr uint32_t kThreads = kSpheres ? kWideSphereBlock : kWideBlock;
+    UnitStream stream{ pb.cursors + 2 * bounce, bounce == 0 ? nullptr : UnitCount( pb, bounce - 1, kCountNextPaths, 0 ), pb.units, kUnitPaths, numPaths };
+    const float4* rayO = pb.rayO[bounce & 1];
+    const float4* rayD = pb.rayD[bounce & 1];
+    const SceneBuffers sb = MakeWideBuffers( sv );
+    __shared__ uint2 stackLds[kWideLdsStack * kThreads];
+    uint2* const myLds   = stackLds + threadIdx.x;
+    uint2* const mySpill = spill + ( static_cast< size_t >( blockIdx.x ) * kThreads + threadIdx.x );
+    const size_t spillStride = static_cast< size_t >( gridDim.x ) * kThreads;
+    uint32_t entry = kNoRay;
+    f3 o = F3( 0.0f, 0.0f, 0.0f ), d = o, inv = o;
+    bool nx = false, ny = false, nz = false;
+    uint32_t octMasks = 0, sp = 0;
+    WideGroup g{ 0u, 0u, 0u };
+    uint32_t ambiguous = 0;
+    HitRecord h{ FLT_MAX, 0.0f, 0.0f, -1 };
+    uint32_t waveRays = 0, waveNodes = 0, waveTris = 0, waveSpheres = 0, waveSteps = 0; // whole-wave totals, wave-uniform
+
+    for ( ;; )
+    {
+        const bool atLeaf = ( g.bits & 0x00FF0000u ) != 0;
+        const bool idle   = ( ( g.bits & 0x00FF00FFu ) | sp ) == 0;
+        const unsigned long long mLeaf = Ballot( atLeaf ), mIdle = Ballot( idle );
+        const unsigned long long mTrav = ~mIdle & ~mLeaf;
+        const unsigned long long mRay  = mIdle & ( stream.ended ? Ballot( entry != kNoRay ) : ~0ull );
+        if ( ( mLeaf | mTrav | mRay ) == 0 ) break;
+
+        if ( mRay && ( __popcll( mRay ) >= PT_WIDE_REFILL_LANES || ( mTrav | mLeaf ) == 0 ) )
+        {
+            if ( idle && entry != kNoRay )
+            {
+                pb.hit[entry] = make_float4( ( ambiguous & kUntrusted ) ? FLT_MAX : h.t, h.u, h.v, __int_as_float( h.prim ) );
+                if ( ambiguous ) pb.redo[atomicAdd( pb.redoCount + bounce, 1u )] = entry;
+                entry = kNoRay;
+            }
+            while ( !stream.ended )
+            {
+                const unsigned long long mAsk = Ballot( idle && entry == kNoRay );
+                if ( mAsk == 0 ) break;
+                if ( stream.taken == stream.count )
+                {
+                    NextUnit( stream );
+                    continue;
+                }
+                const uint32_t left = stream.count - stream.taken, asking = static_cast< uint32_t >( __popcll( mAsk ) );
+                const uint32_t rank = LanesBelow( mAsk );
+                if ( idle && entry == kNoRay && rank < left )
+                {
+                    entry = stream.base + stream.taken + rank;
+                    o   = F3( rayO[entry] );
+                    d   = F3( rayD[entry] );
+                    inv = F3( 1.0f / d.x, 1.0f / d.y, 1.0f / d.z ); // bvh.cpp:235-236
+                    nx = inv.x < 0; ny = inv.y < 0; nz = inv.z < 0;
+                    octMasks  = WideOctMasks( nx, ny, nz );
+                    h         = HitRecord{ FLT_MAX, 0.0f, 0.0f, -1 };     // scene.cpp:372
+                    ambiguous = WideDegenerate( inv ) ? kUntrusted : 0u;  // such a ray goes straight to the second pass
+                    g         = WideGroup{ 0u, 0u, ambiguous ? 0u : 0x0101u };
+                    sp        = 0;
+                }
+                const uint32_t given = asking < left ? asking : left;
+                stream.taken += given;
+                waveRays += given;
+            }
+            continue;
+        }
+
+        if ( mLeaf && ( __popcll( mLeaf ) >= PT_WIDE_LEAF_LANES || mTrav == 0 ) )
+        {
+            for ( ;; )
+            {
+                const uint32_t l = ( g.bits >> 16 ) & 0xFFu;
+                if ( Ballot( l != 0 ) == 0 ) break;
+                bool isTri = false, isSphere = false;
+                if ( l != 0 )
+                {
+                    const uint32_t k = static_cast< uint32_t >( __builtin_ctz( l ) );
+                    g.bits &= ~( 0x10000u << k );
+                    ClosestPrimTestWide< kSpheres >( sv, sb.prims, g.primBase + __popc( ( g.bits >> 24 ) & ( ( 1u << k ) - 1u ) ), o, d, inv, nx, ny, nz, h, &isSphere, &ambiguous );
+                    isTri = !isSphere;
+                }
+                waveTris += LanesSet( isTri );
+                waveSpheres += LanesSet( isSphere );
+            }
+            continue;
+        }
+
+        const uint32_t started = static_cast< uint32_t >( __popcll( mTrav ) );
+        for ( int burst = 0; burst < PT_WIDE_BURST; ++burst )
+        {
+            const bool go = ( g.bits & 0x00FF0000u ) == 0 && ( ( g.bits & 0xFFu ) | sp ) != 0;
+            const uint32_t active = LanesSet( go );
+            if ( burst && 2 * active < started ) break;
+            waveNodes += active;
+            waveSteps++;
+            if ( go )
+            {
+                uint32_t ih = g.bits & 0xFFu, im = ( g.bits >> 8 ) & 0xFFu, base = g.childBase, s;
+                if ( ih == 0 )
+                {
+                    // nothing left of the last node: on with the youngest entry of the stack, which stays if more is left of it
+                    const uint32_t top = sp - 1u;
+                    uint2* slot = top < kWideLdsStack ? myLds + top * kThreads : mySpill + ( top - kWideLdsStack ) * spillStride;
+                    const uint2 e = *slot;
+                    base = e.x;
+                    ih   = e.y & 0xFFu;
+                    im   = e.y >> 8;
+                    s    = WidePick( ih, octMasks );
+                    ih &= ~( 1u << s );
+                    if ( ih )
+                        slot->y = im << 8 | ih;
+                    else
+                        sp = top;
+                }
+                else
+                {
+                    s = WidePick( ih, octMasks );
+                    ih &= ~( 1u << s );
+                    if ( ih )
+                    {
+                        uint2* slot = sp < kWideLdsStack ? myLds + sp * kThreads : mySpill + ( sp - kWideLdsStack ) * spillStride;
+                        *slot = make_uint2( base, im << 8 | ih );
+                        sp++;
+                    }
+                }
+                g = WideVisit< kSpheres >( sb.nodes, base + __popc( im & ( ( 1u << s ) - 1u ) ), o, inv, nx, ny, nz, h.t * kBand );
+            }
+        }
+    }
+    FlushWaveCounter( stats, ST_RAYS_CLOSEST, waveRays );
+    FlushWaveCounter( stats, ST_NODES_CLOSEST, waveNodes );
+    FlushWaveCounter( stats, ST_TRI_CLOSEST, waveTris );
+    FlushWaveCounter( stats, ST_SPH_CLOSEST, waveSpheres );
+    FlushWaveCounter( stats, ST_STEPS_CLOSEST, waveSteps );
 }
 
 // Visibility of the queued shadow rays: BVH::Occluded (src/bvh.cpp:270-310) under Scene::Occluded
@@ -1721,7 +2187,8 @@ __global__ __launch_bounds__( kBlock ) void TonemapKernel( const float4* film, f
 }
 
 // Batch queries behind pt_trace_closest / pt_trace_any: device arrays of n rays, one thread per ray.
-template < bool kOrdered >
+// kMode: PT_TRAVERSAL_*
+template < int kMode >
 __global__ __launch_bounds__( kBlock ) void TraceClosestKernel( SceneView sv, uint64_t n, const float* origins, const float* dirs, int32_t* prim,
                                                                float* t, float* u, float* v, uint32_t* nodes, uint32_t* tests )
 {
@@ -1729,11 +2196,14 @@ __global__ __launch_bounds__( kBlock ) void TraceClosestKernel( SceneView sv, ui
     {
         Counters cnt;
         HitRecord h;
-        if constexpr ( kOrdered )
+        if constexpr ( kMode != PT_TRAVERSAL_REFERENCE )
         {
-            bool ambiguous;
-            h = TraceClosestOrdered( sv, MakeSceneBuffers< true >( sv ), F3( origins + 3 * i ), F3( dirs + 3 * i ), cnt, &ambiguous );
-            if ( ambiguous ) h = RetraceInReferenceOrder( sv, MakeSceneBuffers< false >( sv ), F3( origins + 3 * i ), F3( dirs + 3 * i ), h.t, cnt );
+            uint32_t ambiguous;
+            if constexpr ( kMode == PT_TRAVERSAL_WIDE )
+                h = TraceClosestWide( sv, MakeWideBuffers( sv ), F3( origins + 3 * i ), F3( dirs + 3 * i ), cnt, &ambiguous );
+            else
+                h = TraceClosestOrdered( sv, MakeSceneBuffers< true >( sv ), F3( origins + 3 * i ), F3( dirs + 3 * i ), cnt, &ambiguous );
+            if ( ambiguous ) h = RetraceInReferenceOrder( sv, MakeSceneBuffers< false >( sv ), F3( origins + 3 * i ), F3( dirs + 3 * i ), ( ambiguous & kUntrusted ) ? FLT_MAX : h.t, cnt );
         }
         else
             h = TraceClosest( sv, MakeSceneBuffers< false >( sv ), F3( origins + 3 * i ), F3( dirs + 3 * i ), cnt );
@@ -1746,15 +2216,20 @@ __global__ __launch_bounds__( kBlock ) void TraceClosestKernel( SceneView sv, ui
     }
 }
 
-template < bool kOrdered >
+template < int kMode >
 __global__ __launch_bounds__( kBlock ) void TraceAnyKernel( SceneView sv, uint64_t n, const float* origins, const float* dirs, const float* tMax,
                                                            uint8_t* occluded, uint32_t* nodes, uint32_t* tests )
 {
     for ( uint64_t i = static_cast< uint64_t >( blockIdx.x ) * kBlock + threadIdx.x; i < n; i += static_cast< uint64_t >( gridDim.x ) * kBlock )
     {
         Counters cnt;
-        bool occ = kOrdered ? TraceAnyOrdered( sv, MakeSceneBuffers< true >( sv ), F3( origins + 3 * i ), F3( dirs + 3 * i ), tMax[i], cnt )
-                            : TraceAny( sv, MakeSceneBuffers< false >( sv ), F3( origins + 3 * i ), F3( dirs + 3 * i ), tMax[i], cnt );
+        bool occ;
+        if constexpr ( kMode == PT_TRAVERSAL_WIDE )
+            occ = TraceAnyWide( sv, MakeWideBuffers( sv ), F3( origins + 3 * i ), F3( dirs + 3 * i ), tMax[i], cnt );
+        else if constexpr ( kMode == PT_TRAVERSAL_ORDERED )
+            occ = TraceAnyOrdered( sv, MakeSceneBuffers< true >( sv ), F3( origins + 3 * i ), F3( dirs + 3 * i ), tMax[i], cnt );
+        else
+            occ = TraceAny( sv, MakeSceneBuffers< false >( sv ), F3( origins + 3 * i ), F3( dirs + 3 * i ), tMax[i], cnt );
         occluded[i] = occ ? 1 : 0;
         if ( nodes ) nodes[i] = cnt.nodes;
         if ( tests ) tests[i] = cnt.tris + cnt.spheres;
@@ -1791,8 +2266,28 @@ void LaunchRaygen( const LaunchCfg& cfg, const CameraFrame& cam, const RngParams
     hipLaunchKernelGGL( RaygenKernel, dim3( GridFor( cfg, numPaths ) ), dim3( kBlock ), 0, cfg.stream, cam, rng, pb, width, height, sampleBegin, numPaths );
 }
 
+void WideOccupancy( bool spheres, int* blocksPerCu, int* threadsPerBlock, int* ldsStackEntries )
+{
+    int b = 0;
+    const hipError_t rc = spheres ? hipOccupancyMaxActiveBlocksPerMultiprocessor( &b, ExtendWideKernel< true >, kWideSphereBlock, 0 )
+                                  : hipOccupancyMaxActiveBlocksPerMultiprocessor( &b, ExtendWideKernel< false >, kWideBlock, 0 );
+    if ( rc != hipSuccess || b < 1 ) b = 1;
+    *blocksPerCu     = b;
+    *threadsPerBlock = spheres ? kWideSphereBlock : kWideBlock;
+    *ldsStackEntries = static_cast< int >( kWideLdsStack );
+}
+
 void LaunchExtend( const LaunchCfg& cfg, const SceneView& sv, const PathBuffers& pb, int bounce, uint32_t numPaths, uint64_t* stats )
 {
+    if ( cfg.wide )
+    {
+        if ( sv.numSpheres )
+            hipLaunchKernelGGL( ( ExtendWideKernel< true > ), dim3( cfg.wideBlocks ), dim3( kWideSphereBlock ), 0, cfg.stream, sv, pb, bounce, numPaths, cfg.wideSpill, stats );
+        else
+            hipLaunchKernelGGL( ( ExtendWideKernel< false > ), dim3( cfg.wideBlocks ), dim3( kWideBlock ), 0, cfg.stream, sv, pb, bounce, numPaths, cfg.wideSpill, stats );
+        hipLaunchKernelGGL( RedoKernel, dim3( cfg.blocks > 256 ? cfg.blocks : 256 ), dim3( kBlock ), 0, cfg.stream, sv, pb, bounce, stats );
+        return;
+    }
     const dim3 grid( cfg.extendBlocks ), block( sv.numSpheres ? kTraverseBlock : kTriangleBlock );
     if ( sv.numSpheres && cfg.ordered )
         hipLaunchKernelGGL( ( ExtendKernel< true, true > ), grid, block, 0, cfg.stream, sv, pb, bounce, numPaths, stats );
@@ -1859,19 +2354,23 @@ void LaunchTonemap( const LaunchCfg& cfg, const float4* film, float* linearOut, 
 void LaunchTraceClosest( const LaunchCfg& cfg, const SceneView& sv, uint64_t n, const float* origins, const float* dirs, int32_t* prim,
                          float* t, float* u, float* v, uint32_t* nodes, uint32_t* tests )
 {
-    if ( cfg.ordered )
-        hipLaunchKernelGGL( TraceClosestKernel< true >, dim3( GridFor( cfg, n ) ), dim3( kBlock ), 0, cfg.stream, sv, n, origins, dirs, prim, t, u, v, nodes, tests );
+    if ( cfg.wide )
+        hipLaunchKernelGGL( TraceClosestKernel< PT_TRAVERSAL_WIDE >, dim3( GridFor( cfg, n ) ), dim3( kBlock ), 0, cfg.stream, sv, n, origins, dirs, prim, t, u, v, nodes, tests );
+    else if ( cfg.ordered )
+        hipLaunchKernelGGL( TraceClosestKernel< PT_TRAVERSAL_ORDERED >, dim3( GridFor( cfg, n ) ), dim3( kBlock ), 0, cfg.stream, sv, n, origins, dirs, prim, t, u, v, nodes, tests );
     else
-        hipLaunchKernelGGL( TraceClosestKernel< false >, dim3( GridFor( cfg, n ) ), dim3( kBlock ), 0, cfg.stream, sv, n, origins, dirs, prim, t, u, v, nodes, tests );
+        hipLaunchKernelGGL( TraceClosestKernel< PT_TRAVERSAL_REFERENCE >, dim3( GridFor( cfg, n ) ), dim3( kBlock ), 0, cfg.stream, sv, n, origins, dirs, prim, t, u, v, nodes, tests );
 }
 
 void LaunchTraceAny( const LaunchCfg& cfg, const SceneView& sv, uint64_t n, const float* origins, const float* dirs, const float* tMax,
                      uint8_t* occluded, uint32_t* nodes, uint32_t* tests )
 {
-    if ( cfg.ordered )
-        hipLaunchKernelGGL( TraceAnyKernel< true >, dim3( GridFor( cfg, n ) ), dim3( kBlock ), 0, cfg.stream, sv, n, origins, dirs, tMax, occluded, nodes, tests );
+    if ( cfg.wide )
+        hipLaunchKernelGGL( TraceAnyKernel< PT_TRAVERSAL_WIDE >, dim3( GridFor( cfg, n ) ), dim3( kBlock ), 0, cfg.stream, sv, n, origins, dirs, tMax, occluded, nodes, tests );
+    else if ( cfg.ordered )
+        hipLaunchKernelGGL( TraceAnyKernel< PT_TRAVERSAL_ORDERED >, dim3( GridFor( cfg, n ) ), dim3( kBlock ), 0, cfg.stream, sv, n, origins, dirs, tMax, occluded, nodes, tests );
     else
-        hipLaunchKernelGGL( TraceAnyKernel< false >, dim3( GridFor( cfg, n ) ), dim3( kBlock ), 0, cfg.stream, sv, n, origins, dirs, tMax, occluded, nodes, tests );
+        hipLaunchKernelGGL( TraceAnyKernel< PT_TRAVERSAL_REFERENCE >, dim3( GridFor( cfg, n ) ), dim3( kBlock ), 0, cfg.stream, sv, n, origins, dirs, tMax, occluded, nodes, tests );
 }
 
 } // namespace ptd

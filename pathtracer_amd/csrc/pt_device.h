@@ -9,6 +9,8 @@
 //              lo / hi = the box of the BVH leaf that holds the primitive
 //   shadowNodes  1 x float4 per record, for the shadow rays of a scene lit by one directional light (see
 //              ConnectParallelKernel in kernels.hip), or absent
+//   wideNodes  5 x float4 per node of the tree collapsed to eight children with quantised boxes, widePrims the
+//              primitive records in that tree's order (wide_bvh.h)
 //   triShade   8 x float4 per triangle primitive (112 B used, 128 B apart = one L2 line): n0 n1 n2 t0 t1 t2 uv0 uv1 uv2 material
 //   spheres    6 x float4: world-to-local columns 0..3, {centre, radius}, {material}
 //   materials  2 x float4: {albedo, texture index} {Ke}
@@ -24,6 +26,7 @@ namespace ptd
 
 constexpr uint32_t kInnerNode    = 0xFFFFFFFFu; // "no leaf pending" in the traversal state; never a valid leaf word
 constexpr uint32_t kLeafFlag     = 0x80000000u; // top bit of a node's link word
+constexpr uint32_t kSphereBelowFlag = 0x10u;    // front-to-back layout, second word of a record: the subtree holds a sphere
 constexpr uint32_t kTopNodes     = 4095;          // default size of the top of the tree that is stored first
 constexpr uint32_t kLeafFirstMask = 0x0FFFFFFFu; // leaf word: low 28 bits first primitive, high 4 bits count - 1
 constexpr int kMaxLeafShapes     = 16;
@@ -69,6 +72,10 @@ struct SceneView
     float shadowOrigin[2], shadowInvCell[2]; // shadowNodes: grid coordinate along u = ( dot( p, lightU ) - shadowOrigin[0] ) * shadowInvCell[0]
     uint32_t shadowDepthAxis;   // shadowNodes: the world axis the rays mostly travel along; a record's third word is the box's far plane
     float shadowDepthSign;      // there in the rays' sense: max if they travel up the axis (+1), -min if down (-1)
+    const float4* wideNodes;    // fourth layout (wide_bvh.h): 5 x float4 per node of up to eight children, or nullptr
+    const float4* widePrims;    // the primitive records in the order the wide nodes refer to them
+    uint32_t numWideNodes;
+    uint32_t wideDepth;         // levels of wide nodes: the deepest a traversal stack can get
     const float4* prims;
     const float4* triShade;
     const float4* spheres;
@@ -160,6 +167,9 @@ struct LaunchCfg
     int extendBlocks;  // resident blocks of ExtendKernel
     int connectBlocks; // resident blocks of ConnectKernel
     bool ordered;      // front-to-back traversal over SceneView::orderedNodes
+    bool wide = false; // closest hits over SceneView::wideNodes (implies the rest of `ordered`)
+    int wideBlocks = 0;          // resident blocks of ExtendWideKernel
+    uint2* wideSpill = nullptr;  // stack entries beyond the ones a lane keeps in LDS: [level][thread of the grid]
 };
 
 // --- launch wrappers (kernels.hip) ---------------------------------------------------------------------
@@ -167,6 +177,8 @@ void LaunchRaygen( const LaunchCfg& cfg, const CameraFrame& cam, const RngParams
                    uint32_t width, uint32_t height, uint32_t sampleBegin, uint32_t numPaths );
 // resident blocks per compute unit of the two traversal kernels (occupancy query)
 void TraversalOccupancy( bool spheres, int* extendBlocksPerCu, int* connectBlocksPerCu );
+// resident blocks per compute unit and threads per block of the wide traversal kernel
+void WideOccupancy( bool spheres, int* blocksPerCu, int* threadsPerBlock, int* ldsStackEntries );
 void LaunchExtend( const LaunchCfg& cfg, const SceneView& sv, const PathBuffers& pb, int bounce, uint32_t numPaths, uint64_t* stats );
 void LaunchShade( const LaunchCfg& cfg, const SceneView& sv, const RngParams& rng, const PathBuffers& pb, int bounce,
                   int maxDepth, uint32_t width, uint32_t height, uint32_t sampleBegin, uint32_t numPaths, uint64_t* stats );

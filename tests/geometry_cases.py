@@ -91,4 +91,26 @@ def cases(seed=0):
     tiny = (soup * 2e-4).astype(np.float32)
     o, d = rays_towards(tiny.reshape(-1, 3), n, 1e-5)
     out["coordinates around 1e-4"] = (triangle_scene(tiny), o.astype(np.float32), d.astype(np.float32))
+
+    # Grazing rays: large axis-aligned triangles (boxes of zero thickness) that abut, overlap and coincide, in two
+    # parallel planes and on a wall behind them, met at angles between 1e-7 and 1e-2 of their plane from origins a few
+    # units and up to 1e6 units away.  At such angles the distance a triangle test returns is off by far more than an
+    # ulp, so which of two coplanar hits is the closer one - and whether a box is culled by the first of them - is
+    # decided by noise: the front-to-back modes have to give the reference's answer all the same.
+    big = np.float32(100.0)
+    quad = lambda z: [[[0, 0, z], [big, 0, z], [big, big, z]], [[0, 0, z], [big, big, z], [0, big, z]]]
+    over = lambda z: [[[10, 10, z], [90, 20, z], [50, 90, z]], [[10, 10, z], [90, 20, z], [50, 90, z]], [[30, 5, z], [95, 60, z], [20, 70, z]]]
+    wall = [[[big, 0, -5], [big, big, -5], [big, big, 5]], [[big, 0, -5], [big, big, 5], [big, 0, 5]],
+            [[0, big, -5], [big, big, 5], [big, big, -5]], [[0, big, -5], [0, big, 5], [big, big, 5]]]
+    flat = np.float32(quad(0.0) + over(0.0) + quad(0.5) + over(0.5) + wall)
+    n = 60_000
+    target = np.stack([rng.uniform(0, big, n), rng.uniform(0, big, n), rng.choice([0.0, 0.5], n)], axis=1)
+    target[: n // 4, :2] = np.round(target[: n // 4, :2] / 10) * 10          # on the diagonal, on edges, at corners
+    phi = rng.uniform(0, 2 * np.pi, n)
+    graze = 10.0 ** rng.uniform(-7, -2, n) * rng.choice([-1.0, 1.0], n)
+    dirs = np.stack([np.cos(phi), np.sin(phi), graze], axis=1)
+    dirs *= 10.0 ** rng.uniform(-1, 1, (n, 1))                                  # not normalised, like a bounce direction
+    dist = np.where(rng.integers(0, 2, n) == 0, rng.uniform(1, 10, n), 10.0 ** rng.uniform(3, 6, n))
+    o = target - dirs / np.linalg.norm(dirs, axis=1, keepdims=True) * dist[:, None]
+    out["grazing rays on coplanar triangles"] = (triangle_scene(flat), o.astype(np.float32), dirs.astype(np.float32))
     return out
