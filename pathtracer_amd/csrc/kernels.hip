@@ -539,9 +539,9 @@ __device__ __forceinline__ uint32_t WideBoxes( float4 n0, float4 n2, float4 n3, 
                 iz = __builtin_amdgcn_fmed3f( inv.z, -kWideInvLimit, kWideInvLimit );
     const float ax = __uint_as_float( ( w3 & 0xFFu ) << 23 ) * ix, ay = __uint_as_float( ( w3 & 0xFF00u ) << 15 ) * iy, az = __uint_as_float( ( w3 & 0xFF0000u ) << 7 ) * iz;
     const float bx = ( n0.x - o.x ) * ix, by = ( n0.y - o.y ) * iy, bz = ( n0.z - o.z ) * iz;
-    const float e  = __builtin_fmaxf( __builtin_fmaxf( __builtin_fmaf( fabsf( ax ), 255.0f * kWideSlack, fabsf( bx ) * kWideSlack ),
-                                                       __builtin_fmaf( fabsf( ay ), 255.0f * kWideSlack, fabsf( by ) * kWideSlack ) ),
-                                      __builtin_fmaf( fabsf( az ), 255.0f * kWideSlack, fabsf( bz ) * kWideSlack ) );
+    // E for all three axes at once: the largest |B| and the largest |A| bound every axis' own sum
+    const float e  = __builtin_fmaf( __builtin_fmaxf( __builtin_fmaxf( fabsf( ax ), fabsf( ay ) ), fabsf( az ) ), 255.0f * kWideSlack,
+                                     __builtin_fmaxf( __builtin_fmaxf( fabsf( bx ), fabsf( by ) ), fabsf( bz ) ) * kWideSlack );
     const float e2 = e + e;
     // near planes carry -2 E, so that max( near ) <= min( far ) below is the test with E on either side
     const f2 ax2 = f2{ ax, ax }, ay2 = f2{ ay, ay }, az2 = f2{ az, az };
@@ -1293,10 +1293,10 @@ __global__ __launch_bounds__( kBlock ) void RedoKernel( SceneView sv, PathBuffer
 // the grid and level; the tree's depth bounds the stack, because a level pushes at most one entry.  Results and the
 // queue of rays to trace again are ExtendKernel< ., true >'s.
 #ifndef PT_WIDE_BLOCK
-#define PT_WIDE_BLOCK 1024
+#define PT_WIDE_BLOCK 768
 #endif
 #ifndef PT_WIDE_WAVES
-#define PT_WIDE_WAVES 8
+#define PT_WIDE_WAVES 6
 #endif
 #ifndef PT_WIDE_SPHERE_BLOCK
 #define PT_WIDE_SPHERE_BLOCK 768
@@ -1328,23 +1328,24 @@ void ExtendWideKernel( SceneView sv, PathBuffers pb, int bounce, uint32_t numPat
     const float4* rayO = pb.rayO[bounce & 1];
     const float4* rayD = pb.rayD[bounce & 1];
     const SceneBuffers sb = MakeWideBuffers( sv );
+    // A lane's stack: entries { index of a node's first inner child, its inner slots << 8 | those of them still to visit };
+    // the first kWideLdsStack of them in LDS, entry-major
     __shared__ uint2 stackLds[kWideLdsStack * kThreads];
-    uint2* const myLds   = stackLds + threadIdx.x;
-    uint2* const mySpill = spill + ( static_cast< size_t >( blockIdx.x ) * kThreads + threadIdx.x );
-    const size_t spillStride = static_cast< size_t >( gridDim.x ) * kThreads;
+    uint2* const myLds = stackLds + threadIdx.x;
+    const size_t spillStride = static_cast< size_t >( gridDim.x ) * kThreads, spillLane = static_cast< size_t >( blockIdx.x ) * kThreads + threadIdx.x;
     uint32_t entry = kNoRay;
     f3 o = F3( 0.0f, 0.0f, 0.0f ), d = o, inv = o;
     bool nx = false, ny = false, nz = false;
     uint32_t octMasks = 0, sp = 0;
-    WideGroup g{ 0u, 0u, 0u };
+    uint32_t primBase = 0, leafBits = 0; // of the node visited last: its leaf slots << 8 | those of them hit and not tested yet
     uint32_t ambiguous = 0;
     HitRecord h{ FLT_MAX, 0.0f, 0.0f, -1 };
     uint32_t waveRays = 0, waveNodes = 0, waveTris = 0, waveSpheres = 0, waveSteps = 0; // whole-wave totals, wave-uniform
 
     for ( ;; )
     {
-        const bool atLeaf = ( g.bits & 0x00FF0000u ) != 0;
-        const bool idle   = ( ( g.bits & 0x00FF00FFu ) | sp ) == 0;
+        const bool atLeaf = ( leafBits & 0xFFu ) != 0;
+        const bool idle   = ( ( leafBits & 0xFFu ) | sp ) == 0;
         const unsigned long long mLeaf = Ballot( atLeaf ), mIdle = Ballot( idle );
         const unsigned long long mTrav = ~mIdle & ~mLeaf;
         const unsigned long long mRay  = mIdle & ( stream.ended ? Ballot( entry != kNoRay ) : ~0ull );
@@ -1379,8 +1380,9 @@ void ExtendWideKernel( SceneView sv, PathBuffers pb, int bounce, uint32_t numPat
                     octMasks  = WideOctMasks( nx, ny, nz );
                     h         = HitRecord{ FLT_MAX, 0.0f, 0.0f, -1 };     // scene.cpp:372
                     ambiguous = WideDegenerate( inv ) ? kUntrusted : 0u;  // such a ray goes straight to the second pass
-                    g         = WideGroup{ 0u, 0u, ambiguous ? 0u : 0x0101u };
-                    sp        = 0;
+                    leafBits  = 0;
+                    sp        = ambiguous ? 0u : 1u;
+                    myLds[0]  = make_uint2( 0u, 0x0101u );                // the root as the one child of a node above it
                 }
                 const uint32_t given = asking < left ? asking : left;
                 stream.taken += given;
@@ -1393,14 +1395,14 @@ void ExtendWideKernel( SceneView sv, PathBuffers pb, int bounce, uint32_t numPat
         {
             for ( ;; )
             {
-                const uint32_t l = ( g.bits >> 16 ) & 0xFFu;
+                const uint32_t l = leafBits & 0xFFu;
                 if ( Ballot( l != 0 ) == 0 ) break;
                 bool isTri = false, isSphere = false;
                 if ( l != 0 )
                 {
                     const uint32_t k = static_cast< uint32_t >( __builtin_ctz( l ) );
-                    g.bits &= ~( 0x10000u << k );
-                    ClosestPrimTestWide< kSpheres >( sv, sb.prims, g.primBase + __popc( ( g.bits >> 24 ) & ( ( 1u << k ) - 1u ) ), o, d, inv, nx, ny, nz, h, &isSphere, &ambiguous );
+                    leafBits &= ~( 1u << k );
+                    ClosestPrimTestWide< kSpheres >( sv, sb.prims, primBase + __popc( ( leafBits >> 8 ) & ( ( 1u << k ) - 1u ) ), o, d, inv, nx, ny, nz, h, &isSphere, &ambiguous );
                     isTri = !isSphere;
                 }
                 waveTris += LanesSet( isTri );
@@ -1412,42 +1414,39 @@ void ExtendWideKernel( SceneView sv, PathBuffers pb, int bounce, uint32_t numPat
         const uint32_t started = static_cast< uint32_t >( __popcll( mTrav ) );
         for ( int burst = 0; burst < PT_WIDE_BURST; ++burst )
         {
-            const bool go = ( g.bits & 0x00FF0000u ) == 0 && ( ( g.bits & 0xFFu ) | sp ) != 0;
+            const bool go = ( leafBits & 0xFFu ) == 0 && sp != 0;
             const uint32_t active = LanesSet( go );
             if ( burst && 2 * active < started ) break;
             waveNodes += active;
             waveSteps++;
             if ( go )
             {
-                uint32_t ih = g.bits & 0xFFu, im = ( g.bits >> 8 ) & 0xFFu, base = g.childBase, s;
-                if ( ih == 0 )
-                {
-                    // nothing left of the last node: on with the youngest entry of the stack, which stays if more is left of it
-                    const uint32_t top = sp - 1u;
-                    uint2* slot = top < kWideLdsStack ? myLds + top * kThreads : mySpill + ( top - kWideLdsStack ) * spillStride;
-                    const uint2 e = *slot;
-                    base = e.x;
-                    ih   = e.y & 0xFFu;
-                    im   = e.y >> 8;
-                    s    = WidePick( ih, octMasks );
-                    ih &= ~( 1u << s );
-                    if ( ih )
-                        slot->y = im << 8 | ih;
-                    else
-                        sp = top;
-                }
+                // the youngest entry: visit the nearest of its children, drop the entry if that was the last.  LDS is read
+                // without asking where the entry lives and the rare deeper entry fetched on top: a pointer that may point
+                // to either home makes every access a flat one.
+                const uint32_t top = sp - 1u;
+                uint2 e = myLds[( top < kWideLdsStack ? top : kWideLdsStack - 1u ) * kThreads];
+                asm volatile( "" : "+v"( e.x ), "+v"( e.y ) ); // the LDS read stays an LDS read
+                if ( top >= kWideLdsStack ) e = spill[( top - kWideLdsStack ) * spillStride + spillLane];
+                const uint32_t s = WidePick( e.y & 0xFFu, octMasks );
+                const uint32_t left = e.y & ~( 1u << s );
+                if ( ( left & 0xFFu ) == 0 )
+                    sp = top;
+                else if ( top < kWideLdsStack )
+                    myLds[top * kThreads].y = left;
                 else
+                    spill[( top - kWideLdsStack ) * spillStride + spillLane].y = left;
+                const WideGroup g = WideVisit< kSpheres >( sb.nodes, e.x + __popc( ( e.y >> 8 ) & ( ( 1u << s ) - 1u ) ), o, inv, nx, ny, nz, h.t * kBand );
+                primBase = g.primBase;
+                leafBits = g.bits >> 16;
+                if ( g.bits & 0xFFu )
                 {
-                    s = WidePick( ih, octMasks );
-                    ih &= ~( 1u << s );
-                    if ( ih )
-                    {
-                        uint2* slot = sp < kWideLdsStack ? myLds + sp * kThreads : mySpill + ( sp - kWideLdsStack ) * spillStride;
-                        *slot = make_uint2( base, im << 8 | ih );
-                        sp++;
-                    }
+                    if ( sp < kWideLdsStack )
+                        myLds[sp * kThreads] = make_uint2( g.childBase, g.bits & 0xFFFFu );
+                    else
+                        spill[( sp - kWideLdsStack ) * spillStride + spillLane] = make_uint2( g.childBase, g.bits & 0xFFFFu );
+                    sp++;
                 }
-                g = WideVisit< kSpheres >( sb.nodes, base + __popc( im & ( ( 1u << s ) - 1u ) ), o, inv, nx, ny, nz, h.t * kBand );
             }
         }
     }

@@ -1,7 +1,8 @@
 #!/bin/bash
 # Profiles bench.py on the GPU box: one rocprofv3 kernel trace with statistics, then one run per PMC pass
 # (counters only, never combined with a trace).  usage, from the repository root:
-#   profiles/collect_pmc.sh <tag> [ordered|reference]      bench.py in that traversal order (default ordered)
+#   profiles/collect_pmc.sh <tag> [wide|ordered|reference] bench.py in that traversal mode (default ordered); BENCH_ARGS in
+#                                                          the environment adds arguments (e.g. "--spp-per-step 32")
 #   profiles/collect_pmc.sh <tag> script.py args...        that python script (path relative to the repository
 #                                                          root) instead, with the same arguments in every pass
 # Output: gpurun_out/<tag>/{trace,sq,mem,fetch,write}/ and gpurun_out/<tag>/pmc_summary.{json,txt}
@@ -11,14 +12,14 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 TRAVERSAL=""
-if [ $# -ge 2 ] && [ "$2" != ordered ] && [ "$2" != reference ]; then
+if [ $# -ge 2 ] && [ "$2" != ordered ] && [ "$2" != reference ] && [ "$2" != wide ]; then
   shift
   PROG=$GRAFT_REPO_ROOT/$1; shift
   TRACE_ARGS=("$@"); PASS_ARGS=("$@")
 else
   TRAVERSAL=${2:-ordered}
   PROG=$GRAFT_REPO_ROOT/bench.py
-  TRACE_ARGS=(--steps 4 --warmup 1 --cpu-baseline-spp 0 --traversal $TRAVERSAL); PASS_ARGS=(--steps 1 --warmup 0 --cpu-baseline-spp 0 --traversal $TRAVERSAL)
+  TRACE_ARGS=(--steps 4 --warmup 1 --cpu-baseline-spp 0 --traversal $TRAVERSAL ${BENCH_ARGS:-}); PASS_ARGS=(--steps 1 --warmup 0 --cpu-baseline-spp 0 --traversal $TRAVERSAL ${BENCH_ARGS:-})
 fi
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $PROG "${TRACE_ARGS[@]}" > $OUT/trace.log 2>&1 || exit 1
 run_pass() {

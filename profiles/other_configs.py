@@ -17,22 +17,23 @@ from pathtracer_amd import api, host  # noqa: E402
 from pathtracer_amd.scene import SceneData  # noqa: E402
 
 
-def measure(name, desc, spp, repeats=3, ordered=True, flags=0):
+def measure(name, desc, spp, repeats=3, mode="ordered", flags=0):
+    ordered, wide = mode != "reference", mode == "wide"
     desc.flags |= flags
     t_upload = time.time()
     with api.DeviceScene(desc) as dev:
         t_upload = time.time() - t_upload
-        dev.render(min(spp, 2), seed=1, ordered=ordered)  # warm-up: allocations, code upload
+        dev.render(min(spp, 2), seed=1, ordered=ordered, wide=wide)  # warm-up: allocations, code upload
         dev.readback()
         best = None
         for r in range(repeats):
-            dev.render(spp, seed=r, ordered=ordered, profile=True)
+            dev.render(spp, seed=r, ordered=ordered, wide=wide, profile=True)
             _, _, st = dev.readback()
             if best is None or st.render_ms < best.render_ms:
                 best = st
         rays = best.rays_closest + best.rays_shadow
         print(json.dumps({
-            "config": name, "scene_flags": int(desc.flags), "traversal": "ordered" if ordered else "reference", "width": desc.image_width, "height": desc.image_height, "depth": desc.max_depth, "spp": spp,
+            "config": name, "scene_flags": int(desc.flags), "traversal": mode, "width": desc.image_width, "height": desc.image_height, "depth": desc.max_depth, "spp": spp,
             "triangles": int(desc.num_triangles), "nodes": int(desc.num_nodes),
             "samples": int(best.samples), "rays": int(rays), "render_ms": round(best.render_ms, 3),
             "mrays_per_s": round(rays / best.render_ms * 1e-3, 1),
@@ -50,14 +51,15 @@ def measure(name, desc, spp, repeats=3, ordered=True, flags=0):
 def main():
     p = argparse.ArgumentParser()
     p.add_argument("--soup-triangles", type=int, default=20_000_000)
-    p.add_argument("--traversal", choices=("ordered", "reference", "both"), default="both")
+    p.add_argument("--traversal", choices=("wide", "ordered", "reference", "both", "all"), default="all")
     p.add_argument("--scene-flags", type=int, default=0, help="PT_SCENE_* measurement switches for every upload")
     a = p.parse_args()
-    modes = {"ordered": [True], "reference": [False], "both": [False, True]}[a.traversal]
+    modes = {"wide": ["wide"], "ordered": ["ordered"], "reference": ["reference"], "both": ["reference", "ordered"],
+             "all": ["reference", "ordered", "wide"]}[a.traversal]
 
     cornell = SceneData.load(os.path.join(ROOT, "tests", "golden", "cornell_scene.npz")).with_image(1024, 1024)
     for m in modes:
-        measure("cornell 1024^2 (configs[1])", cornell.to_desc(), 256, ordered=m, flags=a.scene_flags)
+        measure("cornell 1024^2 (configs[1])", cornell.to_desc(), 256, mode=m, flags=a.scene_flags)
 
     t = time.time()
     with host.HostScene.knot(seed=2, triangles=871414) as hs:
@@ -65,13 +67,13 @@ def main():
         hs.set_max_depth(1)
         print(f"knot scene: {time.time() - t:.1f} s", file=sys.stderr)
         for m in modes:
-            measure("knot 871k 4K primary + shadow (configs[3])", hs.desc(), 16, ordered=m, flags=a.scene_flags)
+            measure("knot 871k 4K primary + shadow (configs[3])", hs.desc(), 16, mode=m, flags=a.scene_flags)
 
     t = time.time()
     with host.HostScene.soup(seed=3, triangles=a.soup_triangles, edge=0.01, skybox_size=1024) as hs:
         print(f"soup scene: {time.time() - t:.1f} s", file=sys.stderr)
         for m in modes:
-            measure("soup 4K depth 5 (configs[4])", hs.desc(), 8, ordered=m, flags=a.scene_flags)
+            measure("soup 4K depth 5 (configs[4])", hs.desc(), 8, mode=m, flags=a.scene_flags)
 
 
 if __name__ == "__main__":

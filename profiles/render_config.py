@@ -17,7 +17,7 @@ p.add_argument("--spp", type=int, default=4)
 p.add_argument("--width", type=int, default=0)
 p.add_argument("--height", type=int, default=0)
 p.add_argument("--depth", type=int, default=-1)
-p.add_argument("--traversal", choices=("ordered", "reference"), default="ordered")
+p.add_argument("--traversal", choices=("wide", "ordered", "reference"), default="ordered")
 a = p.parse_args()
 
 if a.scene == "soup":
@@ -32,7 +32,7 @@ with hs:
     if a.depth >= 0:
         hs.set_max_depth(a.depth)
     with api.DeviceScene(hs.desc()) as dev:
-        dev.render(a.spp, seed=0, ordered=a.traversal == "ordered")
+        dev.render(a.spp, seed=0, ordered=a.traversal != "reference", wide=a.traversal == "wide")
         _, _, st = dev.readback()
         rays = st.rays_closest + st.rays_shadow
         print(json.dumps({"scene": a.scene, "spp": a.spp, "rays": int(rays), "render_ms": st.render_ms,
