@@ -68,6 +68,7 @@ def parse():
     p.add_argument("--traversal", choices=("wide", "ordered", "reference"), default="ordered",
                    help="child visiting order of the BVH traversal: front to back (default; same hits and film, fewer node "
                         "visits) or the reference's first-child-first order (counters equal to the CPU's)")
+    p.add_argument("--wide-shadows", action="store_true", help="shadow rays over the eight-wide layout too (PT_RENDER_WIDE_SHADOWS)")
     p.add_argument("--scene-flags", type=int, default=0, help="PT_SCENE_* flags for pt_upload_scene (measurement switches)")
     p.add_argument("--cpu-baseline-spp", type=int, default=64, help="most samples per pixel the CPU baseline renders (0 = skip)")
     p.add_argument("--cpu-baseline-seconds", type=float, default=20.0, help="CPU time the baseline sample is sized for")
@@ -137,7 +138,7 @@ def main():
             first = (step * world + rank) * spp_step
             last = first + spp_step
         if last > first:
-            dev.render(spp_total, first, last, seed=args.seed, accumulate=True, profile=profile, ordered=ordered, wide=wide)
+            dev.render(spp_total, first, last, seed=args.seed, accumulate=True, profile=profile, ordered=ordered, wide=wide, wide_shadows=args.wide_shadows)
 
     # CPU baseline beside the GPU number, rank 0 at N = 1 only, before the GPU's warm-up: the reference's own compiled
     # Li / BVH / shape code (oracle/_ref/libptref.so, built from /root/reference in the build container) when that

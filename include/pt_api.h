@@ -218,8 +218,11 @@ enum
     PT_RENDER_ORDERED    = 1u << 2, /* front-to-back traversal, see PT_TRAVERSAL_ORDERED; in a scene lit by one
                                        directional light the shadow rays, all parallel, are traced in the light's
                                        space (same occlusion answers, other node counts)                          */
-    PT_RENDER_WIDE       = 1u << 3  /* PT_RENDER_ORDERED with the closest hits found over the eight-wide layout, see
+    PT_RENDER_WIDE       = 1u << 3, /* PT_RENDER_ORDERED with the closest hits found over the eight-wide layout, see
                                        PT_TRAVERSAL_WIDE: the same film, a fifth of the node visits                  */
+    PT_RENDER_WIDE_SHADOWS = 1u << 4 /* the shadow rays over the eight-wide layout as well, whatever the lights (in place
+                                       of the light-space search of PT_RENDER_ORDERED and of the reference-order tree):
+                                       same occlusion answers, same film                                             */
 };
 
 /* Order in which a ray visits the children of an inner BVH node.

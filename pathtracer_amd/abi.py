@@ -14,7 +14,7 @@ PT_PRIM_TRIANGLE, PT_PRIM_SPHERE = 0, 1
 PT_LIGHT_POINT, PT_LIGHT_DIRECTIONAL, PT_LIGHT_AREA = 0, 1, 2
 PT_RNG_PHILOX, PT_RNG_TABLE = 0, 1
 PT_TONEMAP_UNCHARTED2, PT_TONEMAP_REINHARD, PT_TONEMAP_NONE = 0, 1, 2
-PT_RENDER_ACCUMULATE, PT_RENDER_PROFILE, PT_RENDER_ORDERED, PT_RENDER_WIDE = 1, 2, 4, 8
+PT_RENDER_ACCUMULATE, PT_RENDER_PROFILE, PT_RENDER_ORDERED, PT_RENDER_WIDE, PT_RENDER_WIDE_SHADOWS = 1, 2, 4, 8, 16
 PT_TRAVERSAL_REFERENCE, PT_TRAVERSAL_ORDERED, PT_TRAVERSAL_WIDE = 0, 1, 2
 PT_TRACE_STATIC_MAX_RAYS = 262144
 PT_SCENE_NO_DIRECT_SUM, PT_SCENE_TOP_BREADTH_FIRST, PT_SCENE_NO_ORDERED_LAYOUT, PT_SCENE_NO_PARALLEL_SHADOWS = 1, 2, 4, 8

@@ -121,13 +121,14 @@ class DeviceScene:
         self.close()
 
     def render(self, spp_total, sample_begin=0, sample_end=None, seed=0, table=None, table_draws_per_sample=0,
-               accumulate=False, profile=False, samples_per_pass=0, stream=None, ordered=False, wide=False):
+               accumulate=False, profile=False, samples_per_pass=0, stream=None, ordered=False, wide=False, wide_shadows=False):
         """ordered: front-to-back traversal (PT_RENDER_ORDERED) - same film, fewer node visits; wide: the same with
-        the closest hits found over the eight-wide node layout (PT_RENDER_WIDE)."""
+        the closest hits found over the eight-wide node layout (PT_RENDER_WIDE); wide_shadows: the shadow rays over that
+        layout too (PT_RENDER_WIDE_SHADOWS)."""
         p = abi.PtRenderParams()
         p.struct_size = C.sizeof(abi.PtRenderParams)
         p.flags = ((abi.PT_RENDER_ACCUMULATE if accumulate else 0) | (abi.PT_RENDER_PROFILE if profile else 0)
-                   | (abi.PT_RENDER_ORDERED if ordered else 0) | (abi.PT_RENDER_WIDE if wide else 0))
+                   | (abi.PT_RENDER_ORDERED if ordered else 0) | (abi.PT_RENDER_WIDE if wide else 0) | (abi.PT_RENDER_WIDE_SHADOWS if wide_shadows else 0))
         p.spp_total = int(spp_total)
         p.sample_begin = int(sample_begin)
         p.sample_end = int(spp_total if sample_end is None else sample_end)

@@ -249,6 +249,7 @@ struct PtScene
     int gridBlocks = 2048;
     int extendBlocks = 1024, connectBlocks = 1024; // resident grids of the traversal kernels
     int wideBlocks = 512, wideThreads = 1024, wideLdsStack = 8; // the wide closest-hit kernel: resident grid, block size, stack entries it keeps in LDS
+    int wideShadowBlocks = 512, wideShadowThreads = 768;       // the wide any-hit kernel
     uint32_t topNodes = 0;                          // nodes at the front of the device array in breadth-first order
     bool directSum = false;                         // one light with one sample: ConnectKernel adds the direct light, no ResolveKernel
 
@@ -853,8 +854,9 @@ int Upload( PtScene* s, const PtSceneDesc* d, const std::vector< uint32_t >& esc
                 }
             } );
             HIP_TRY( s->widePrims.Upload( ordered.get(), 64ull * P ) );
-            if ( wideDepth > static_cast< uint32_t >( s->wideLdsStack ) )
-                HIP_TRY( s->wideSpill.Allocate( 8ull * ( wideDepth - s->wideLdsStack ) * static_cast< uint64_t >( s->wideBlocks ) * s->wideThreads ) );
+            // stack entries beyond the ones the kernels keep in LDS: one slot per level and thread of the larger of the two grids
+            const uint64_t lanes = std::max< uint64_t >( static_cast< uint64_t >( s->wideBlocks ) * s->wideThreads, static_cast< uint64_t >( s->wideShadowBlocks ) * s->wideShadowThreads );
+            if ( wideDepth > static_cast< uint32_t >( s->wideLdsStack ) ) HIP_TRY( s->wideSpill.Allocate( 8ull * ( wideDepth - s->wideLdsStack ) * lanes ) );
         }
     }
     prims.reset();
@@ -1130,6 +1132,9 @@ try
         int widePerCu = 1;
         WideOccupancy( desc->num_spheres > 0, &widePerCu, &s->wideThreads, &s->wideLdsStack );
         s->wideBlocks = widePerCu * cus;
+        int shadowPerCu = 1;
+        WideShadowOccupancy( &shadowPerCu, &s->wideShadowThreads );
+        s->wideShadowBlocks = shadowPerCu * cus;
     }
     hipError_t e = hipStreamCreate( &s->stream );
     if ( e != hipSuccess ) return Fail( PT_ERR_DEVICE, "hipStreamCreate failed: %s", hipGetErrorString( e ) );
@@ -1250,12 +1255,15 @@ try
     }
 
     const CameraFrame cam = MakeCameraFrame( s->camera, s->width, s->height );
+    const bool wideShadows = ( p->flags & PT_RENDER_WIDE_SHADOWS ) != 0;
     const bool wide    = ( p->flags & PT_RENDER_WIDE ) != 0;
     const bool ordered = ( p->flags & PT_RENDER_ORDERED ) != 0 || wide;
-    if ( wide && !s->wideNodes.ptr ) return Fail( PT_ERR_STATE, "pt_render: PT_RENDER_WIDE, but the scene has no wide layout (PT_SCENE_NO_WIDE_LAYOUT, or a tree it cannot express)" );
+    if ( ( wide || wideShadows ) && !s->wideNodes.ptr ) return Fail( PT_ERR_STATE, "pt_render: PT_RENDER_WIDE / PT_RENDER_WIDE_SHADOWS, but the scene has no wide layout (PT_SCENE_NO_WIDE_LAYOUT, or a tree it cannot express)" );
     if ( ordered && !wide && !s->orderedNodes.ptr ) return Fail( PT_ERR_STATE, "pt_render: PT_RENDER_ORDERED, but the scene was uploaded with PT_SCENE_NO_ORDERED_LAYOUT" );
     LaunchCfg cfg{ stream, s->gridBlocks, s->extendBlocks, s->connectBlocks, ordered };
     cfg.wide       = wide;
+    cfg.wideShadows = wideShadows;
+    cfg.wideShadowBlocks = s->wideShadowBlocks;
     cfg.wideBlocks = s->wideBlocks;
     cfg.wideSpill  = s->wideSpill.As< uint2 >();
     SpanTimer timer{ s, stream, ( p->flags & PT_RENDER_PROFILE ) != 0 };

@@ -489,18 +489,28 @@ __device__ __forceinline__ bool TraceAnyOrdered( const SceneView& sv, const Scen
 // with A = cell * inv (exact: cell is a power of two) and B = fl( fl( p - o ) * inv ).  With u = 2^-24:
 //   |t~ - ( X - o ) inv| <= 2.02 u |B| + 1.01 u |t~|,   |t - ( L - o ) inv| <= 2.01 u ( 1.01 |B| + 255 |A| ),
 //   |t~| <= ( |B| + 255 |A| )( 1 + u ),
-// so t >= t~ - E for a near plane and t <= t~ + E for a far plane with E = 2^-21 ( |B| + 255 |A| ) (6.1 u would do).
+// so t >= t~ - E for a near plane and t <= t~ + E for a far plane with E = 2^-21 ( |B| + 255 |A| ) (6.1 u would do), per axis.
 // The reference passes a box only if max( near ) <= min( far ), max( near ) <= limit and min( far ) > 0; the test
-// below passes whenever max( near~ ) - E <= min( far~ ) + E, max( near~ ) - E <= limit and min( far~ ) + E >= 0, E the
-// largest of the three axes'.  Anything that is not a number passes (comparisons are written so that a NaN enters).
+// below passes whenever max( near~ - E ) <= min( far~ + E ), max( near~ - E ) <= limit and min( far~ + E ) >= 0.
+// Anything that is not a number passes (comparisons are written so that a NaN enters).
 // A direction component of zero makes inv infinite, and the reference's slab test on that axis a containment test
 // of the origin, whatever the magnitude of inv: the wide test uses 2^100 in its place, which keeps the arithmetic
-// finite.  A ray with a finite reciprocal beyond 2^100 (a direction component below 2^-100) is not traversed here at
-// all: it is handed to the pass in the reference's order like an ambiguous one.
+// finite.  A finite reciprocal beyond 2^100 (a direction component below 2^-100) takes its axis out of the test
+// (WideInv); a closest-hit ray with one is not traversed here at all but handed to the pass in the reference's order.
 constexpr uint32_t kWideNodeBytes = 80u;
 constexpr float kWideInvLimit = 1.2676506002282294e30f; // 2^100
 constexpr float kWideSlack = 1.0f / 2097152.0f;          // 2^-21
 constexpr uint32_t kWideStackEntries = 56;                // kWideMaxDepth of wide_bvh.h
+
+// The reciprocal direction as the wide box test takes it: an infinite component (direction component zero) as 2^100 of its
+// sign, and a finite one beyond 2^100 as a NaN - whatever is computed from it is then not a number, and the maxima and
+// minima of the test pass over such operands: the axis is left out of the test, which only lets more through.
+__device__ __forceinline__ float WideInvComponent( float x )
+{
+    const float a = fabsf( x );
+    return ( a > kWideInvLimit && a < INFINITY ) ? __builtin_nanf( "" ) : __builtin_amdgcn_fmed3f( x, -kWideInvLimit, kWideInvLimit );
+}
+__device__ __forceinline__ f3 WideInv( f3 inv ) { return F3( WideInvComponent( inv.x ), WideInvComponent( inv.y ), WideInvComponent( inv.z ) ); }
 
 __device__ __forceinline__ bool WideDegenerate( f3 inv )
 {
@@ -535,18 +545,17 @@ template < bool kUnlimited = false >
 __device__ __forceinline__ uint32_t WideBoxes( float4 n0, float4 n2, float4 n3, float4 n4, f3 o, f3 inv, bool nx, bool ny, bool nz, float limit )
 {
     const uint32_t w3 = __float_as_uint( n0.w );
-    const float ix = __builtin_amdgcn_fmed3f( inv.x, -kWideInvLimit, kWideInvLimit ), iy = __builtin_amdgcn_fmed3f( inv.y, -kWideInvLimit, kWideInvLimit ),
-                iz = __builtin_amdgcn_fmed3f( inv.z, -kWideInvLimit, kWideInvLimit );
+    const float ix = inv.x, iy = inv.y, iz = inv.z; // WideInv of the ray's reciprocal direction
     const float ax = __uint_as_float( ( w3 & 0xFFu ) << 23 ) * ix, ay = __uint_as_float( ( w3 & 0xFF00u ) << 15 ) * iy, az = __uint_as_float( ( w3 & 0xFF0000u ) << 7 ) * iz;
     const float bx = ( n0.x - o.x ) * ix, by = ( n0.y - o.y ) * iy, bz = ( n0.z - o.z ) * iz;
-    // E for all three axes at once: the largest |B| and the largest |A| bound every axis' own sum
-    const float e  = __builtin_fmaf( __builtin_fmaxf( __builtin_fmaxf( fabsf( ax ), fabsf( ay ) ), fabsf( az ) ), 255.0f * kWideSlack,
-                                     __builtin_fmaxf( __builtin_fmaxf( fabsf( bx ), fabsf( by ) ), fabsf( bz ) ) * kWideSlack );
-    const float e2 = e + e;
-    // near planes carry -2 E, so that max( near ) <= min( far ) below is the test with E on either side
+    // every axis with its own E: a direction along an axis (the shadow rays of a light straight above) has bounds of the
+    // order 2^100 on the other two, which must not loosen the one that counts
+    const float ex = __builtin_fmaf( fabsf( ax ), 255.0f * kWideSlack, fabsf( bx ) * kWideSlack ), ey = __builtin_fmaf( fabsf( ay ), 255.0f * kWideSlack, fabsf( by ) * kWideSlack ),
+                ez = __builtin_fmaf( fabsf( az ), 255.0f * kWideSlack, fabsf( bz ) * kWideSlack );
+    // near planes carry -E, far planes +E: max( near ) <= min( far ) below is then the test with E on either side
     const f2 ax2 = f2{ ax, ax }, ay2 = f2{ ay, ay }, az2 = f2{ az, az };
-    const f2 bx2 = f2{ bx - e2, bx }, by2 = f2{ by - e2, by }, bz2 = f2{ bz - e2, bz };
-    const float lower = -e, upper = limit - e;
+    const f2 bx2 = f2{ bx - ex, bx + ex }, by2 = f2{ by - ey, by + ey }, bz2 = f2{ bz - ez, bz + ez };
+    const float lower = 0.0f, upper = limit;
     const uint32_t lox[2] = { __float_as_uint( n2.x ), __float_as_uint( n2.y ) }, loy[2] = { __float_as_uint( n2.z ), __float_as_uint( n2.w ) },
                    loz[2] = { __float_as_uint( n3.x ), __float_as_uint( n3.y ) }, hix[2] = { __float_as_uint( n3.z ), __float_as_uint( n3.w ) },
                    hiy[2] = { __float_as_uint( n4.x ), __float_as_uint( n4.y ) }, hiz[2] = { __float_as_uint( n4.z ), __float_as_uint( n4.w ) };
@@ -654,6 +663,7 @@ __device__ __forceinline__ HitRecord TraceClosestWide( const SceneView& sv, cons
     *ambiguous    = WideDegenerate( inv ) ? kUntrusted : 0u;
     if ( *ambiguous ) return h;
     const uint32_t octMasks = WideOctMasks( nx, ny, nz );
+    const f3 invW = WideInv( inv );
     uint2 stack[kWideStackEntries];
     uint32_t sp = 0;
     WideGroup g{ 0u, 0u, 0x0101u }; // the root as the one child of a node above it
@@ -671,7 +681,7 @@ __device__ __forceinline__ HitRecord TraceClosestWide( const SceneView& sv, cons
         const uint32_t s = WidePick( ih, octMasks );
         ih &= ~( 1u << s );
         if ( ih && sp < kWideStackEntries ) stack[sp++] = make_uint2( base, im << 8 | ih );
-        g = WideVisit< true >( sb.nodes, base + __popc( im & ( ( 1u << s ) - 1u ) ), o, inv, nx, ny, nz, h.t * kBand );
+        g = WideVisit< true >( sb.nodes, base + __popc( im & ( ( 1u << s ) - 1u ) ), o, invW, nx, ny, nz, h.t * kBand );
         cnt.nodes++;
         const uint32_t lmask = g.bits >> 24;
         for ( uint32_t l = ( g.bits >> 16 ) & 0xFFu; l; l &= l - 1u )
@@ -692,8 +702,8 @@ __device__ __forceinline__ bool TraceAnyWide( const SceneView& sv, const SceneBu
 {
     const f3 inv  = F3( 1.0f / d.x, 1.0f / d.y, 1.0f / d.z );
     const bool nx = inv.x < 0, ny = inv.y < 0, nz = inv.z < 0;
-    if ( WideDegenerate( inv ) ) return TraceAny( sv, MakeSceneBuffers< false >( sv ), o, d, tMax, cnt );
     const uint32_t octMasks = WideOctMasks( nx, ny, nz );
+    const f3 invW = WideInv( inv );
     uint2 stack[kWideStackEntries];
     uint32_t sp = 0;
     WideGroup g{ 0u, 0u, 0x0101u };
@@ -711,7 +721,7 @@ __device__ __forceinline__ bool TraceAnyWide( const SceneView& sv, const SceneBu
         const uint32_t s = WidePick( ih, octMasks );
         ih &= ~( 1u << s );
         if ( ih && sp < kWideStackEntries ) stack[sp++] = make_uint2( base, im << 8 | ih );
-        g = WideVisit( sb.nodes, base + __popc( im & ( ( 1u << s ) - 1u ) ), o, inv, nx, ny, nz, tMax );
+        g = WideVisit( sb.nodes, base + __popc( im & ( ( 1u << s ) - 1u ) ), o, invW, nx, ny, nz, tMax );
         cnt.nodes++;
         const uint32_t lmask = g.bits >> 24;
         for ( uint32_t l = ( g.bits >> 16 ) & 0xFFu; l; l &= l - 1u )
@@ -1334,7 +1344,7 @@ void ExtendWideKernel( SceneView sv, PathBuffers pb, int bounce, uint32_t numPat
     uint2* const myLds = stackLds + threadIdx.x;
     const size_t spillStride = static_cast< size_t >( gridDim.x ) * kThreads, spillLane = static_cast< size_t >( blockIdx.x ) * kThreads + threadIdx.x;
     uint32_t entry = kNoRay;
-    f3 o = F3( 0.0f, 0.0f, 0.0f ), d = o, inv = o;
+    f3 o = F3( 0.0f, 0.0f, 0.0f ), d = o, inv = o, invW = o;
     bool nx = false, ny = false, nz = false;
     uint32_t octMasks = 0, sp = 0;
     uint32_t primBase = 0, leafBits = 0; // of the node visited last: its leaf slots << 8 | those of them hit and not tested yet
@@ -1378,6 +1388,7 @@ void ExtendWideKernel( SceneView sv, PathBuffers pb, int bounce, uint32_t numPat
                     inv = F3( 1.0f / d.x, 1.0f / d.y, 1.0f / d.z ); // bvh.cpp:235-236
                     nx = inv.x < 0; ny = inv.y < 0; nz = inv.z < 0;
                     octMasks  = WideOctMasks( nx, ny, nz );
+                    invW      = WideInv( inv );
                     h         = HitRecord{ FLT_MAX, 0.0f, 0.0f, -1 };     // scene.cpp:372
                     ambiguous = WideDegenerate( inv ) ? kUntrusted : 0u;  // such a ray goes straight to the second pass
                     leafBits  = 0;
@@ -1436,7 +1447,7 @@ void ExtendWideKernel( SceneView sv, PathBuffers pb, int bounce, uint32_t numPat
                     myLds[top * kThreads].y = left;
                 else
                     spill[( top - kWideLdsStack ) * spillStride + spillLane].y = left;
-                const WideGroup g = WideVisit< kSpheres >( sb.nodes, e.x + __popc( ( e.y >> 8 ) & ( ( 1u << s ) - 1u ) ), o, inv, nx, ny, nz, h.t * kBand );
+                const WideGroup g = WideVisit< kSpheres >( sb.nodes, e.x + __popc( ( e.y >> 8 ) & ( ( 1u << s ) - 1u ) ), o, invW, nx, ny, nz, h.t * kBand );
                 primBase = g.primBase;
                 leafBits = g.bits >> 16;
                 if ( g.bits & 0xFFu )
@@ -1626,6 +1637,156 @@ __global__ __launch_bounds__( kConnectBlock ) PT_CONNECT_OCCUPANCY void ConnectK
                         node = link & ~kLeafFlag;
                         if ( boxHit ) leaf = word;
                     }
+                }
+            }
+        }
+    }
+    FlushWaveCounter( stats, ST_RAYS_SHADOW, waveRays );
+    FlushWaveCounter( stats, ST_NODES_SHADOW, waveNodes );
+    FlushWaveCounter( stats, ST_TRI_SHADOW, waveTris );
+    FlushWaveCounter( stats, ST_SPH_SHADOW, waveSpheres );
+    FlushWaveCounter( stats, ST_STEPS_SHADOW, waveSteps );
+}
+
+// ConnectKernel over the wide layout: any hit, with ExtendWideKernel's stack and scheduling.  The order of the search
+// does not matter to the answer: a primitive counts only if the reference's own test of its leaf box against the ray's
+// fixed tMax passes (AnyPrimTestWide), which is the condition under which BVH::Occluded reaches it.
+template < bool kDirectSum >
+__global__ __launch_bounds__( kWideBlock ) __attribute__( ( amdgpu_waves_per_eu( PT_WIDE_WAVES, PT_WIDE_WAVES ) ) )
+void ConnectWideKernel( SceneView sv, PathBuffers pb, int bounce, uint2* spill, uint64_t* stats )
+{
+    constexpr uint32_t kThreads = kWideBlock;
+    UnitStream stream{ pb.cursors + 2 * bounce + 1, UnitCount( pb, bounce, kCountShadowRays, 0 ), pb.units, kUnitPaths * pb.shadowSlots, 0u };
+    const uint32_t entries = pb.units * kUnitPaths;
+    const SceneBuffers sb  = MakeWideBuffers( sv );
+    __shared__ uint2 stackLds[kWideLdsStack * kThreads];
+    uint2* const myLds = stackLds + threadIdx.x;
+    const size_t spillStride = static_cast< size_t >( gridDim.x ) * kThreads, spillLane = static_cast< size_t >( blockIdx.x ) * kThreads + threadIdx.x;
+    uint32_t rec = kNoRay;
+    f3 o = F3( 0.0f, 0.0f, 0.0f ), d = o, inv = o, invW = o;
+    float tMax = 0.0f;
+    bool nx = false, ny = false, nz = false, occluded = false;
+    uint32_t octMasks = 0, sp = 0, primBase = 0, leafBits = 0;
+    uint32_t waveRays = 0, waveNodes = 0, waveTris = 0, waveSpheres = 0, waveSteps = 0; // whole-wave totals, wave-uniform
+
+    for ( ;; )
+    {
+        const bool atLeaf = ( leafBits & 0xFFu ) != 0;
+        const bool idle   = ( ( leafBits & 0xFFu ) | sp ) == 0;
+        const unsigned long long mLeaf = Ballot( atLeaf ), mIdle = Ballot( idle );
+        const unsigned long long mTrav = ~mIdle & ~mLeaf;
+        const unsigned long long mRay  = mIdle & ( stream.ended ? Ballot( rec != kNoRay ) : ~0ull );
+        if ( ( mLeaf | mTrav | mRay ) == 0 ) break;
+
+        if ( mRay && ( __popcll( mRay ) >= PT_WIDE_REFILL_LANES || ( mTrav | mLeaf ) == 0 ) )
+        {
+            if constexpr ( kDirectSum )
+            {
+                if ( idle && rec != kNoRay && !occluded )
+                {
+                    const float4 e = pb.shEst[rec];
+                    const uint32_t p = __float_as_uint( e.w );
+                    pb.rad[p] = F4( F3( pb.rad[p] ) + F3( e ), 0.0f );
+                }
+            }
+            else if ( idle && rec != kNoRay && occluded )
+                reinterpret_cast< float* >( pb.shDir )[4ull * rec + 3] = -2.0f;
+            if ( idle ) rec = kNoRay;
+            while ( !stream.ended )
+            {
+                const unsigned long long mAsk = Ballot( idle && rec == kNoRay );
+                if ( mAsk == 0 ) break;
+                if ( stream.taken == stream.count )
+                {
+                    NextUnit( stream );
+                    continue;
+                }
+                const uint32_t left = stream.count - stream.taken, asking = static_cast< uint32_t >( __popcll( mAsk ) );
+                const uint32_t rank = LanesBelow( mAsk );
+                if ( idle && rec == kNoRay && rank < left )
+                {
+                    rec = pb.shadowRays[stream.base + stream.taken + rank];
+                    uint32_t entry = pb.shadowSlots == 1 ? rec : rec % entries; // record index = slot * entries + entry
+                    asm volatile( "" : "+v"( entry ) );                              // the index first, then both loads in one go
+                    float4 dir = pb.shDir[rec];
+                    float4 org = pb.shadowO[entry];
+                    asm volatile( "" : "+v"( dir.x ), "+v"( org.x ) ); // both loads in flight before either is waited for
+                    o    = F3( org );
+                    d    = F3( dir );
+                    tMax = dir.w;
+                    inv  = F3( 1.0f / d.x, 1.0f / d.y, 1.0f / d.z ); // bvh.cpp:275-276
+                    nx = inv.x < 0; ny = inv.y < 0; nz = inv.z < 0;
+                    octMasks = WideOctMasks( nx, ny, nz );
+                    invW     = WideInv( inv );
+                    leafBits = 0;
+                    occluded = false;
+                    sp       = 1u;
+                    myLds[0] = make_uint2( 0u, 0x0101u ); // the root as the one child of a node above it
+                }
+                const uint32_t given = asking < left ? asking : left;
+                stream.taken += given;
+                waveRays += given;
+            }
+            continue;
+        }
+
+        if ( mLeaf && ( __popcll( mLeaf ) >= PT_WIDE_LEAF_LANES || mTrav == 0 ) )
+        {
+            for ( ;; )
+            {
+                const uint32_t l = leafBits & 0xFFu;
+                if ( Ballot( l != 0 ) == 0 ) break;
+                bool isTri = false, isSphere = false;
+                if ( l != 0 )
+                {
+                    const uint32_t k = static_cast< uint32_t >( __builtin_ctz( l ) );
+                    leafBits &= ~( 1u << k );
+                    if ( AnyPrimTestWide( sb.prims, primBase + __popc( ( leafBits >> 8 ) & ( ( 1u << k ) - 1u ) ), o, d, inv, nx, ny, nz, tMax, &isSphere ) )
+                    {
+                        occluded = true; // bvh.cpp:287-293: stop at the first hit
+                        leafBits = 0;
+                        sp       = 0;
+                    }
+                    isTri = !isSphere;
+                }
+                waveTris += LanesSet( isTri );
+                waveSpheres += LanesSet( isSphere );
+            }
+            continue;
+        }
+
+        const uint32_t started = static_cast< uint32_t >( __popcll( mTrav ) );
+        for ( int burst = 0; burst < PT_WIDE_BURST; ++burst )
+        {
+            const bool go = ( leafBits & 0xFFu ) == 0 && sp != 0;
+            const uint32_t active = LanesSet( go );
+            if ( burst && 2 * active < started ) break;
+            waveNodes += active;
+            waveSteps++;
+            if ( go )
+            {
+                const uint32_t top = sp - 1u;
+                uint2 e = myLds[( top < kWideLdsStack ? top : kWideLdsStack - 1u ) * kThreads];
+                asm volatile( "" : "+v"( e.x ), "+v"( e.y ) ); // the LDS read stays an LDS read
+                if ( top >= kWideLdsStack ) e = spill[( top - kWideLdsStack ) * spillStride + spillLane];
+                const uint32_t s = WidePick( e.y & 0xFFu, octMasks );
+                const uint32_t left = e.y & ~( 1u << s );
+                if ( ( left & 0xFFu ) == 0 )
+                    sp = top;
+                else if ( top < kWideLdsStack )
+                    myLds[top * kThreads].y = left;
+                else
+                    spill[( top - kWideLdsStack ) * spillStride + spillLane].y = left;
+                const WideGroup g = WideVisit< false >( sb.nodes, e.x + __popc( ( e.y >> 8 ) & ( ( 1u << s ) - 1u ) ), o, invW, nx, ny, nz, tMax );
+                primBase = g.primBase;
+                leafBits = g.bits >> 16;
+                if ( g.bits & 0xFFu )
+                {
+                    if ( sp < kWideLdsStack )
+                        myLds[sp * kThreads] = make_uint2( g.childBase, g.bits & 0xFFFFu );
+                    else
+                        spill[( sp - kWideLdsStack ) * spillStride + spillLane] = make_uint2( g.childBase, g.bits & 0xFFFFu );
+                    sp++;
                 }
             }
         }
@@ -2265,6 +2426,15 @@ void LaunchRaygen( const LaunchCfg& cfg, const CameraFrame& cam, const RngParams
     hipLaunchKernelGGL( RaygenKernel, dim3( GridFor( cfg, numPaths ) ), dim3( kBlock ), 0, cfg.stream, cam, rng, pb, width, height, sampleBegin, numPaths );
 }
 
+// The any-hit kernel over the wide layout: resident blocks per compute unit (its blocks have kWideBlock threads)
+void WideShadowOccupancy( int* blocksPerCu, int* threadsPerBlock )
+{
+    int b = 0;
+    if ( hipOccupancyMaxActiveBlocksPerMultiprocessor( &b, ConnectWideKernel< true >, kWideBlock, 0 ) != hipSuccess || b < 1 ) b = 1;
+    *blocksPerCu     = b;
+    *threadsPerBlock = kWideBlock;
+}
+
 void WideOccupancy( bool spheres, int* blocksPerCu, int* threadsPerBlock, int* ldsStackEntries )
 {
     int b = 0;
@@ -2316,6 +2486,14 @@ void LaunchShade( const LaunchCfg& cfg, const SceneView& sv, const RngParams& rn
 // every step reads a third word and the LDS copy holds half as many records: +11 % per launch).
 void LaunchConnect( const LaunchCfg& cfg, const SceneView& sv, const PathBuffers& pb, int bounce, uint64_t* stats )
 {
+    if ( cfg.wideShadows )
+    {
+        if ( pb.directSum )
+            hipLaunchKernelGGL( ( ConnectWideKernel< true > ), dim3( cfg.wideShadowBlocks ), dim3( kWideBlock ), 0, cfg.stream, sv, pb, bounce, cfg.wideSpill, stats );
+        else
+            hipLaunchKernelGGL( ( ConnectWideKernel< false > ), dim3( cfg.wideShadowBlocks ), dim3( kWideBlock ), 0, cfg.stream, sv, pb, bounce, cfg.wideSpill, stats );
+        return;
+    }
     const dim3 grid( cfg.connectBlocks ), block( kConnectBlock );
     if ( cfg.ordered && sv.shadowNodes && pb.directSum )
         hipLaunchKernelGGL( ( ConnectParallelKernel< true > ), grid, block, 0, cfg.stream, sv, pb, bounce, stats );

@@ -168,6 +168,8 @@ struct LaunchCfg
     int connectBlocks; // resident blocks of ConnectKernel
     bool ordered;      // front-to-back traversal over SceneView::orderedNodes
     bool wide = false; // closest hits over SceneView::wideNodes (implies the rest of `ordered`)
+    bool wideShadows = false;    // shadow rays over SceneView::wideNodes (ConnectWideKernel)
+    int wideShadowBlocks = 0;    // resident blocks of ConnectWideKernel
     int wideBlocks = 0;          // resident blocks of ExtendWideKernel
     uint2* wideSpill = nullptr;  // stack entries beyond the ones a lane keeps in LDS: [level][thread of the grid]
 };
@@ -179,6 +181,7 @@ void LaunchRaygen( const LaunchCfg& cfg, const CameraFrame& cam, const RngParams
 void TraversalOccupancy( bool spheres, int* extendBlocksPerCu, int* connectBlocksPerCu );
 // resident blocks per compute unit and threads per block of the wide traversal kernel
 void WideOccupancy( bool spheres, int* blocksPerCu, int* threadsPerBlock, int* ldsStackEntries );
+void WideShadowOccupancy( int* blocksPerCu, int* threadsPerBlock );
 void LaunchExtend( const LaunchCfg& cfg, const SceneView& sv, const PathBuffers& pb, int bounce, uint32_t numPaths, uint64_t* stats );
 void LaunchShade( const LaunchCfg& cfg, const SceneView& sv, const RngParams& rng, const PathBuffers& pb, int bounce,
                   int maxDepth, uint32_t width, uint32_t height, uint32_t sampleBegin, uint32_t numPaths, uint64_t* stats );

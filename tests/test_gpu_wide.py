@@ -60,6 +60,15 @@ def check_render(dev, desc, spp, seed, what):
     for c in ("samples", "rays_closest", "rays_shadow", "shaded_hits"):
         assert getattr(stats, c) == getattr(ref_stats, c), c
     assert ref_stats.rays_redone == 0
+    dev.render(spp, seed=seed, wide=True, wide_shadows=True)
+    film2, _, stats2 = dev.readback(abi.PT_TONEMAP_NONE, tonemapped=False)
+    differing = int((film2.view(np.uint32) != ref_film.view(np.uint32)).any(axis=-1).sum())
+    print(f"{what}: {differing} pixels differ with the shadow rays over the wide layout too; visits per shadow ray "
+          f"{ref_stats.nodes_shadow / max(1, ref_stats.rays_shadow):.1f} binary -> {stats2.nodes_shadow / max(1, stats2.rays_shadow):.1f}, "
+          f"primitive tests {ref_stats.tri_tests_shadow / max(1, ref_stats.rays_shadow):.2f} -> {stats2.tri_tests_shadow / max(1, stats2.rays_shadow):.2f}")
+    assert differing == 0, what
+    for c in ("samples", "rays_closest", "rays_shadow", "shaded_hits"):
+        assert getattr(stats2, c) == getattr(ref_stats, c), c
     return film, stats
 
 
