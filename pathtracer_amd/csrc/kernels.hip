@@ -495,7 +495,7 @@ __device__ __forceinline__ bool TraceAnyOrdered( const SceneView& sv, const Scen
 // Anything that is not a number passes (comparisons are written so that a NaN enters).
 // A direction component of zero makes inv infinite, and the reference's slab test on that axis a containment test
 // of the origin, whatever the magnitude of inv: the wide test uses 2^100 in its place, which keeps the arithmetic
-// finite.  A finite reciprocal beyond 2^100 (a direction component below 2^-100) takes its axis out of the test
+// finite.  A finite reciprocal of 2^100 or more (a direction component below 2^-100) takes its axis out of the test
 // (WideInv); a closest-hit ray with one is not traversed here at all but handed to the pass in the reference's order.
 constexpr uint32_t kWideNodeBytes = 80u;
 constexpr float kWideInvLimit = 1.2676506002282294e30f; // 2^100
@@ -508,14 +508,14 @@ constexpr uint32_t kWideStackEntries = 56;                // kWideMaxDepth of wi
 __device__ __forceinline__ float WideInvComponent( float x )
 {
     const float a = fabsf( x );
-    return ( a > kWideInvLimit && a < INFINITY ) ? __builtin_nanf( "" ) : __builtin_amdgcn_fmed3f( x, -kWideInvLimit, kWideInvLimit );
+    return ( a >= kWideInvLimit && a < INFINITY ) ? __builtin_nanf( "" ) : __builtin_amdgcn_fmed3f( x, -kWideInvLimit, kWideInvLimit );
 }
 __device__ __forceinline__ f3 WideInv( f3 inv ) { return F3( WideInvComponent( inv.x ), WideInvComponent( inv.y ), WideInvComponent( inv.z ) ); }
 
 __device__ __forceinline__ bool WideDegenerate( f3 inv )
 {
     const float ax = fabsf( inv.x ), ay = fabsf( inv.y ), az = fabsf( inv.z );
-    return ( ax > kWideInvLimit && ax < INFINITY ) || ( ay > kWideInvLimit && ay < INFINITY ) || ( az > kWideInvLimit && az < INFINITY );
+    return ( ax >= kWideInvLimit && ax < INFINITY ) || ( ay >= kWideInvLimit && ay < INFINITY ) || ( az >= kWideInvLimit && az < INFINITY );
 }
 
 // Per axis the slots a ray prefers - those on the side it comes from -, z in the low byte, then y, then x
@@ -1344,9 +1344,9 @@ void ExtendWideKernel( SceneView sv, PathBuffers pb, int bounce, uint32_t numPat
     uint2* const myLds = stackLds + threadIdx.x;
     const size_t spillStride = static_cast< size_t >( gridDim.x ) * kThreads, spillLane = static_cast< size_t >( blockIdx.x ) * kThreads + threadIdx.x;
     uint32_t entry = kNoRay;
-    f3 o = F3( 0.0f, 0.0f, 0.0f ), d = o, inv = o, invW = o;
+    f3 o = F3( 0.0f, 0.0f, 0.0f ), d = o, invW = o; // invW: WideInv of the reciprocal direction
     bool nx = false, ny = false, nz = false;
-    uint32_t octMasks = 0, sp = 0;
+    uint32_t sp = 0;
     uint32_t primBase = 0, leafBits = 0; // of the node visited last: its leaf slots << 8 | those of them hit and not tested yet
     uint32_t ambiguous = 0;
     HitRecord h{ FLT_MAX, 0.0f, 0.0f, -1 };
@@ -1385,9 +1385,8 @@ void ExtendWideKernel( SceneView sv, PathBuffers pb, int bounce, uint32_t numPat
                     entry = stream.base + stream.taken + rank;
                     o   = F3( rayO[entry] );
                     d   = F3( rayD[entry] );
-                    inv = F3( 1.0f / d.x, 1.0f / d.y, 1.0f / d.z ); // bvh.cpp:235-236
+                    const f3 inv = F3( 1.0f / d.x, 1.0f / d.y, 1.0f / d.z ); // bvh.cpp:235-236
                     nx = inv.x < 0; ny = inv.y < 0; nz = inv.z < 0;
-                    octMasks  = WideOctMasks( nx, ny, nz );
                     invW      = WideInv( inv );
                     h         = HitRecord{ FLT_MAX, 0.0f, 0.0f, -1 };     // scene.cpp:372
                     ambiguous = WideDegenerate( inv ) ? kUntrusted : 0u;  // such a ray goes straight to the second pass
@@ -1413,6 +1412,11 @@ void ExtendWideKernel( SceneView sv, PathBuffers pb, int bounce, uint32_t numPat
                 {
                     const uint32_t k = static_cast< uint32_t >( __builtin_ctz( l ) );
                     leafBits &= ~( 1u << k );
+                    // the reciprocal direction itself, for the reference's box test: invW but for the infinities it replaced
+                    // (a ray with a component WideInv takes out never gets here)
+                    const f3 inv = F3( fabsf( invW.x ) == kWideInvLimit ? __builtin_copysignf( INFINITY, invW.x ) : invW.x,
+                                       fabsf( invW.y ) == kWideInvLimit ? __builtin_copysignf( INFINITY, invW.y ) : invW.y,
+                                       fabsf( invW.z ) == kWideInvLimit ? __builtin_copysignf( INFINITY, invW.z ) : invW.z );
                     ClosestPrimTestWide< kSpheres >( sv, sb.prims, primBase + __popc( ( leafBits >> 8 ) & ( ( 1u << k ) - 1u ) ), o, d, inv, nx, ny, nz, h, &isSphere, &ambiguous );
                     isTri = !isSphere;
                 }
@@ -1439,7 +1443,7 @@ void ExtendWideKernel( SceneView sv, PathBuffers pb, int bounce, uint32_t numPat
                 uint2 e = myLds[( top < kWideLdsStack ? top : kWideLdsStack - 1u ) * kThreads];
                 asm volatile( "" : "+v"( e.x ), "+v"( e.y ) ); // the LDS read stays an LDS read
                 if ( top >= kWideLdsStack ) e = spill[( top - kWideLdsStack ) * spillStride + spillLane];
-                const uint32_t s = WidePick( e.y & 0xFFu, octMasks );
+                const uint32_t s = WidePick( e.y & 0xFFu, WideOctMasks( nx, ny, nz ) );
                 const uint32_t left = e.y & ~( 1u << s );
                 if ( ( left & 0xFFu ) == 0 )
                     sp = top;
