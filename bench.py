@@ -11,25 +11,23 @@ the same triangle count (262,267), camera, light and 24 textured 1024^2 material
 
 One step = one pass of the hot path over one batch: --spp-per-step samples of every pixel (default 128, all in
 flight at once: 265 M paths, 48 GB of path state), i.e. 1920 * 1080 * 128 = 265.4 M pixel samples per GPU and
-step.  --scaling weak (default): every rank renders its own --spp-per-step samples per step, per-GPU work per step
-is fixed.  --scaling strong: the frame is fixed - step k is samples [k * S, (k + 1) * S) of the frame, S =
---spp-per-step, and the ranks share them (pathtracer_amd.path_tracer.sample_range), so --steps 8 is the 1024 spp frame
-of the configuration whatever the number of GPUs.  After the last step the per-GPU films are summed onto rank 0 with
-one RCCL reduce, inside the timed region.  The default --steps 8 on one GPU is the full 1024 spp frame.
+step.  --scaling weak (default): every rank renders its own --spp-per-step samples per step.  --scaling strong: step k
+is samples [k * S * N, (k + 1) * S * N) of ONE frame, S = --spp-per-step, N = ranks, cut into contiguous shares
+(pathtracer_amd.path_tracer.sample_range), so the ranks together render one picture of S * N * steps samples per pixel;
+a rank still renders S samples per pass, because a small pass pays the drain tail of every traversal launch.  The JSON
+line says which of the two it measured.  After the last step the per-GPU films are summed onto rank 0 with one RCCL
+reduce, inside the timed region.  The default --steps 8 on one GPU is the full 1024 spp frame.
 
 The JSON line carries `roofline` for the dominant kernel (closest-hit traversal or shadow-ray traversal, whichever
-took longer).  The scene's 50 MB of nodes and primitive records live in the caches, so the memory system does not
-bound that kernel; the CUs' own units do.  `frac` is therefore the share of the SIMDs' vector issue slots the kernel
-uses (rocprofv3's VALUBusy: SQ_ACTIVE_INST_VALU * 4 / SIMDs / cycles) or the share of time its texture addressers -
-the unit every vector memory instruction passes through - are busy (TA_TA_BUSY / CUs / cycles), whichever is
-higher (`ceilings` lists all three with the memory system), taken from the committed counter summary of this same
-command under profiles/ - only while that summary was collected with the same kernel sources and traversal order;
-otherwise the line says so and falls back to the compulsory bytes.  Beside it, measured live: the kernel's average launch time from HIP events on the
-launch stream, its algorithmic bytes (the reference's per-ray byte model times the kernel's own counters) and,
-under `hbm`, those bytes, the bytes that left the L2 (same summary) and the compulsory bytes (scene records once,
-rays in, hits out) per launch as fractions of the 8 TB/s HBM peak.  `cpu_baseline`: the reference's own compiled
-hot path (oracle/_ref/libptref.so) or, without it, the CPU restatement (oracle/pt_oracle.c), both OpenMP, timed on
-this host over a bounded sample of the same frame, before the GPU's warm-up.
+took longer): the bytes that left the L2 per launch - from the committed counter summary of this same command under
+profiles/, used only while it was collected with the same sources, traversal mode and workload - over the launch's time,
+against the 8 TB/s HBM peak.  The scene's records (a few tens of MB) live in the caches, so that fraction is small: memory
+does not bound the kernel, and `ceilings` lists the units that do (vector issue of the SIMDs, texture addressers, scalar
+units; `binding_unit` names the busiest).  Beside it, measured live: the kernel's average launch time from HIP events on
+the launch stream, its algorithmic bytes (the reference's per-ray byte model times the kernel's own counters) and the
+compulsory bytes (scene records once, rays in, hits out).  `cpu_baseline`: the reference's own compiled hot path
+(oracle/_ref/libptref.so) or, without it, the CPU restatement (oracle/pt_oracle.c), both OpenMP, timed on this host over
+a bounded sample of the same frame, before the GPU's warm-up.
 """
 import argparse
 import glob
@@ -42,7 +40,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
-KERNEL_SOURCES = ("pathtracer_amd/csrc/kernels.hip", "pathtracer_amd/csrc/pt_device.h", "pathtracer_amd/csrc/pt_sincosf.h", "pathtracer_amd/csrc/pt_powf.h", "pathtracer_amd/csrc/pt_acosf.h")
+# everything that decides what the render kernels execute and what they read: the kernels, and the code that lays the scene out for them
+KERNEL_SOURCES = ("pathtracer_amd/csrc/kernels.hip", "pathtracer_amd/csrc/api.hip", "pathtracer_amd/csrc/wide_bvh.hip", "pathtracer_amd/csrc/wide_bvh.h",
+                  "pathtracer_amd/csrc/pt_device.h", "pathtracer_amd/csrc/pt_sincosf.h", "pathtracer_amd/csrc/pt_powf.h", "pathtracer_amd/csrc/pt_acosf.h",
+                  "include/pt_api.h")
 
 
 def kernel_source_hash():
@@ -65,10 +66,11 @@ def parse():
     p.add_argument("--triangles", type=int, default=262267)
     p.add_argument("--texture-size", type=int, default=1024)
     p.add_argument("--seed", type=int, default=0)
-    p.add_argument("--traversal", choices=("wide", "ordered", "reference"), default="ordered",
-                   help="child visiting order of the BVH traversal: front to back (default; same hits and film, fewer node "
-                        "visits) or the reference's first-child-first order (counters equal to the CPU's)")
-    p.add_argument("--wide-shadows", action="store_true", help="shadow rays over the eight-wide layout too (PT_RENDER_WIDE_SHADOWS)")
+    p.add_argument("--traversal", choices=("wide", "ordered", "reference"), default="wide",
+                   help="wide (default): the tree collapsed to eight children per node with quantised boxes, for closest hits and "
+                        "shadow rays; ordered: front to back over the binary tree; reference: the reference's first-child-first "
+                        "order (counters equal to the CPU's).  The same hits and film from each")
+    p.add_argument("--no-wide-shadows", action="store_true", help="with --traversal wide: shadow rays as under --traversal ordered")
     p.add_argument("--scene-flags", type=int, default=0, help="PT_SCENE_* flags for pt_upload_scene (measurement switches)")
     p.add_argument("--cpu-baseline-spp", type=int, default=64, help="most samples per pixel the CPU baseline renders (0 = skip)")
     p.add_argument("--cpu-baseline-seconds", type=float, default=20.0, help="CPU time the baseline sample is sized for")
@@ -126,19 +128,23 @@ def main():
 
     spp_step = args.spp_per_step
     strong = args.scaling == "strong"
-    spp_total = spp_step * (1 if strong else world) * (args.steps + args.warmup)
+    # Either way a rank renders spp_step samples per pixel in a step, as one pass: small passes pay the drain tail of every
+    # traversal launch.  weak: rank r's samples of step k are its own block of the frame; strong: step k is samples
+    # [k * S * N, (k + 1) * S * N) of the frame, S = spp_step, N = ranks, cut into N contiguous shares.
+    spp_total = spp_step * world * (args.steps + args.warmup)
     wide = args.traversal == "wide"
+    wide_shadows = wide and not args.no_wide_shadows
     ordered = args.traversal == "ordered" or wide
 
     def run_step(step, profile):
         if strong:   # this rank's share of the step's samples of the frame
-            begin, end = path_tracer.sample_range(spp_step, rank, world)
-            first, last = step * spp_step + begin, step * spp_step + end
+            begin, end = path_tracer.sample_range(spp_step * world, rank, world)
+            first, last = step * spp_step * world + begin, step * spp_step * world + end
         else:
             first = (step * world + rank) * spp_step
             last = first + spp_step
         if last > first:
-            dev.render(spp_total, first, last, seed=args.seed, accumulate=True, profile=profile, ordered=ordered, wide=wide, wide_shadows=args.wide_shadows)
+            dev.render(spp_total, first, last, seed=args.seed, accumulate=True, profile=profile, ordered=ordered, wide=wide, wide_shadows=wide_shadows)
 
     # CPU baseline beside the GPU number, rank 0 at N = 1 only, before the GPU's warm-up: the reference's own compiled
     # Li / BVH / shape code (oracle/_ref/libptref.so, built from /root/reference in the build container) when that
@@ -208,32 +214,42 @@ def main():
         # dominant traversal kernel on this rank, timed with HIP events around every launch (PT_RENDER_PROFILE)
         ms = {abi.KERNEL_NAMES[i]: stats.kernel_ms[i] for i in range(abi.PT_K_COUNT)}
         launches = {abi.KERNEL_NAMES[i]: int(stats.launches[i] - warm.launches[i]) for i in range(abi.PT_K_COUNT)}
-        # a node visit reads its box and two words (32 B), in the front-to-back order also the ray's link (36 B)
-        node_bytes = 36 if ordered else 32
-        bytes_closest = node_bytes * mine["nodes_closest"] + 48 * mine["tri_tests_closest"] + 84 * mine["sphere_tests_closest"] + 48 * mine["rays_closest"]
-        # shadow rays of a scene lit by one directional light read 16-byte records in the light's frame (front-to-back mode)
+        # Algorithmic bytes, per kernel: what the traversal asks of memory by the reference's per-ray byte model (a node
+        # visit reads the node, a primitive test the primitive's vertices, a ray comes in and a hit goes out), with the
+        # record sizes of the layout the mode reads.  Binary tree: 32 B per node (reference order), 36 B front to back
+        # (the ray's link), 48 B per triangle test.  Eight-wide layout: 80 B per node, 64 B per primitive record (its
+        # vertices and the box of its leaf).  Light-space records of a directional light's shadow rays: 16 B.
         one_directional = desc.num_lights == 1 and int(_from_ptr(desc.lights, 1, abi.LIGHT_DTYPE)["type"][0]) == abi.PT_LIGHT_DIRECTIONAL
-        light_space = ordered and one_directional and not (desc.flags & abi.PT_SCENE_NO_PARALLEL_SHADOWS)
-        bytes_shadow = (16 if light_space else 32) * mine["nodes_shadow"] + 48 * mine["tri_tests_shadow"] + 16 * mine["sphere_tests_shadow"] + 36 * mine["rays_shadow"]
-        # records of the scene the kernel reads at least once (device sizes), beside the rays in and the results out
-        scene_bytes = int(desc.num_nodes) * (64 if ordered else 32) + int(desc.num_prims) * 64
+        light_space = ordered and not wide_shadows and one_directional and not (desc.flags & abi.PT_SCENE_NO_PARALLEL_SHADOWS)
+        node_bytes, prim_bytes = (80, 64) if wide else ((36, 48) if ordered else (32, 48))
+        bytes_closest = node_bytes * mine["nodes_closest"] + prim_bytes * mine["tri_tests_closest"] + 84 * mine["sphere_tests_closest"] + 48 * mine["rays_closest"]
+        shadow_node_bytes, shadow_prim_bytes = (80, 64) if wide_shadows else ((16, 48) if light_space else (32, 48))
+        bytes_shadow = shadow_node_bytes * mine["nodes_shadow"] + shadow_prim_bytes * mine["tri_tests_shadow"] + 16 * mine["sphere_tests_shadow"] + 36 * mine["rays_shadow"]
+        # records of the scene a kernel reads at least once (device sizes), beside the rays in and the results out
+        binary_scene = int(desc.num_nodes) * (64 if ordered else 32) + int(desc.num_prims) * 64
+        wide_scene = int(desc.num_nodes) * 25 + int(desc.num_prims) * 64    # about 0.3 wide nodes of 80 B per node of the tree
         if ms["extend"] >= ms["connect"]:
-            kernel, kbytes, kms, klaunch, krays = "ExtendKernel", bytes_closest, ms["extend"], launches["extend"], mine["rays_closest"]
+            kernel, kbytes, kms, klaunch, krays = ("ExtendWideKernel" if wide else "ExtendKernel"), bytes_closest, ms["extend"], launches["extend"], mine["rays_closest"]
             knodes, ksteps = mine["nodes_closest"], mine["node_steps_closest"]
-            instance = lambda name: name.startswith("ExtendKernel<") and name.rstrip(">").split(",")[-1].strip() == ("true" if ordered else "false")
-            compulsory = scene_bytes * klaunch + 48 * krays
+            if wide:
+                instance = lambda name: name.startswith("ExtendWideKernel<")
+            else:
+                instance = lambda name: name.startswith("ExtendKernel<") and name.rstrip(">").split(",")[-1].strip() == ("true" if ordered else "false")
+            compulsory = (wide_scene if wide else binary_scene) * klaunch + 48 * krays
         else:
-            kernel, kbytes, kms, klaunch, krays = "ConnectKernel", bytes_shadow, ms["connect"], launches["connect"], mine["rays_shadow"]
+            kernel, kbytes, kms, klaunch, krays = ("ConnectWideKernel" if wide_shadows else "ConnectKernel"), bytes_shadow, ms["connect"], launches["connect"], mine["rays_shadow"]
             knodes, ksteps = mine["nodes_shadow"], mine["node_steps_shadow"]
-            instance = lambda name: name.startswith("ConnectKernel<") and name.rstrip(">").split(",")[-1].strip() == "false"
-            compulsory = (int(desc.num_nodes) * 32 + int(desc.num_prims) * 64) * klaunch + 36 * krays
+            prefix = "ConnectWideKernel<" if wide_shadows else ("ConnectParallelKernel<" if light_space else "ConnectKernel<")
+            instance = lambda name: name.startswith(prefix)
+            compulsory = (wide_scene if wide_shadows else int(desc.num_nodes) * 32 + int(desc.num_prims) * 64) * klaunch + 36 * krays
         launch_s = kms * 1e-3 / max(1, klaunch)
         algorithmic_gbs = kbytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
         compulsory_gbs = compulsory / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
 
         # Hardware counters of that kernel from the committed rocprofv3 summary of this same command
-        # (profiles/collect_pmc.sh): used only if it was collected with the same kernel sources, traversal order and
-        # workload, so that a stale summary never sits beside fresh timings.
+        # (profiles/collect_pmc.sh): used only if it was collected with the same sources (kernels and scene layout code),
+        # traversal mode and workload, so that a stale summary never sits beside fresh timings.
+        mode = args.traversal + ("" if wide_shadows or not wide else "-no-wide-shadows")
         profile, profile_name, why_not = None, None, "no counter summary under profiles/"
         default_workload = (args.spp_per_step, args.width, args.height, args.triangles, args.texture_size) == (128, 1920, 1080, 262267, 1024)
         for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")), reverse=True):
@@ -246,8 +262,8 @@ def main():
                 why_not = "the committed counter summaries are of the default workload"
             elif meta.get("kernel_sources") != kernel_source_hash():
                 why_not = f"{os.path.relpath(path, ROOT)} was collected with other kernel sources"
-            elif meta.get("traversal") != args.traversal:
-                why_not = f"{os.path.relpath(path, ROOT)} was collected with the other traversal order"
+            elif meta.get("traversal") != mode:
+                why_not = f"{os.path.relpath(path, ROOT)} was collected in another traversal mode"
             else:
                 name = next((k for k in sorted(summary) if instance(k)), None)
                 if name and "per_dispatch" in summary[name]:
@@ -256,9 +272,10 @@ def main():
         hbm = {"peak": HBM_PEAK_GBS, "unit": "GB/s",
                "algorithmic": round(algorithmic_gbs, 1), "algorithmic_frac": round(algorithmic_gbs / HBM_PEAK_GBS, 4),
                "compulsory": round(compulsory_gbs, 1), "compulsory_frac": round(compulsory_gbs / HBM_PEAK_GBS, 4),
-               "note": "algorithmic = the reference's per-ray byte model times the kernel's own counters (cache hits included, "
-                       "can exceed the HBM peak); compulsory = scene records once per launch + rays in + results out; "
-                       "fabric = bytes that left the L2 per launch (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, Infinity Cache hits included)"}
+               "note": "fabric = bytes that left the L2 per launch, Infinity Cache hits included (FETCH_SIZE as it is for these "
+                       "kernels' gathers of 64-byte lines - calibrated in profiles/r03_fetch_size_calibration.txt - plus WRITE_SIZE); "
+                       "algorithmic = the reference's per-ray byte model times the kernel's own counters (cache hits included, "
+                       "can exceed the HBM peak); compulsory = scene records once per launch + rays in + results out"}
         traffic = None
         if profile:
             per = profile["per_dispatch"]
@@ -267,24 +284,20 @@ def main():
             prof_s = profile.get("trace", {}).get("avg_ns", 0.0) * 1e-9 or launch_s
             busy = per.get("SQ_ACTIVE_INST_VALU", 0.0) * 4                    # SIMD cycles spent issuing vector instructions
             hbm.update({"fabric": round(traffic / prof_s / 1e9, 1), "fabric_frac": round(traffic / prof_s / 1e9 / HBM_PEAK_GBS, 4)})
-            # The ceilings, each as busy cycles of the unit over the cycles it had: the SIMDs' vector issue (1,024
-            # SIMDs; rocprofv3's VALUBusy), the texture addressers through which every vector memory instruction
-            # passes (one per CU; TA_TA_BUSY), the scalar units (one per CU), and the memory system behind the L2 (bytes
-            # against the HBM peak).
+            # The roofline this tier asks for is the memory one: bytes that left the L2 per launch over the launch's time,
+            # against the HBM peak.  The scene's records sit in the caches, so that fraction is small and says that memory
+            # does not bound the kernel; `ceilings` says what does - each unit as busy cycles over the cycles it had: the
+            # SIMDs' vector issue (1,024 SIMDs; SQ_ACTIVE_INST_VALU counts four cycles an instruction, which is what most
+            # vector instructions occupy a SIMD for: profiles/microbench/valu_rate.hip), the texture addressers through
+            # which every vector memory instruction passes (one per CU; TA_TA_BUSY), the scalar units (one per CU).
             ta_busy = per.get("TA_TA_BUSY_sum", 0.0)
             ceilings = {"valu_issue": (busy, 1024 * cycles), "texture_addresser": (ta_busy, 256 * cycles)}
             if per.get("SQ_INSTS_SALU"):   # one scalar unit per CU, at most one instruction per cycle
                 ceilings["scalar_issue"] = (per["SQ_INSTS_SALU"], 256 * cycles)
             fracs = {k: round(a / b, 4) if b else 0.0 for k, (a, b) in ceilings.items()}
             fracs["hbm"] = hbm["fabric_frac"]
-            bound = max(fracs, key=fracs.get)
-            if bound == "hbm":
-                roofline = {"bound": "hbm", "kernel": kernel, "achieved": hbm["fabric"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fracs["hbm"]}
-            else:
-                a, b = ceilings[bound]
-                roofline = {"bound": bound, "kernel": kernel, "achieved": round(a / prof_s / 1e9, 1), "peak": round(b / prof_s / 1e9, 1),
-                            "unit": "G busy cycles/s of the unit, chip-wide", "frac": fracs[bound]}
-            roofline["ceilings"] = fracs
+            roofline = {"bound": "hbm", "kernel": kernel, "achieved": hbm["fabric"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fracs["hbm"],
+                        "binding_unit": max(fracs, key=fracs.get), "ceilings": fracs}
             roofline.update({"counters_from": profile_name, "counters_kernel_sources": kernel_source_hash(),
                              "counters_avg_launch_ms": round(prof_s * 1e3, 4),
                              "counters": {k: round(profile[k], 4) for k in ("l1_hit_rate", "l2_hit_rate", "wave_time_waiting_on_memory",
@@ -293,7 +306,7 @@ def main():
             # without matching counters only the compulsory bytes are known to have moved
             roofline = {"bound": "hbm", "kernel": kernel, "achieved": round(compulsory_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(compulsory_gbs / HBM_PEAK_GBS, 4), "counters_from": None, "counters_missing_because": why_not}
-        roofline.update({"traffic": traffic, "hbm": hbm, "traversal": args.traversal,
+        roofline.update({"traffic": traffic, "hbm": hbm, "traversal": mode,
                          "bytes_per_launch": round(kbytes / max(1, klaunch)), "avg_launch_ms": round(kms / max(1, klaunch), 4),
                          "launches": klaunch, "bytes_per_ray": round(kbytes / max(1, krays), 1),
                          "grays_per_s_in_kernel": round(krays / (kms * 1e-3) / 1e9, 3) if kms > 0 else 0.0,
@@ -329,10 +342,11 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"sponza.json stand-in (procedural atrium, {args.triangles} triangles, 24 textured materials "
                                    f"{args.texture_size}^2, camera/light of resources/scenes/sponza.json) {args.width}x{args.height}, "
-                                   f"depth 5, {spp_step} spp per step" + (" shared by the GPUs" if strong else " and GPU"),
-                       "traversal": args.traversal,
-                       "spp_rendered": spp_step * (1 if strong else world) * args.steps,
-                       "sample_split": f"{spp_step} spp per step over {world} GPU(s)" if strong else f"{world} x {spp_step} spp per step",
+                                   f"depth 5, {spp_step} spp per step and GPU",
+                       "traversal": mode,
+                       "spp_rendered": spp_step * world * args.steps,
+                       "sample_split": (f"strong: every step is {spp_step * world} spp of one frame, shared by {world} GPU(s)" if strong
+                                        else f"weak: {world} x {spp_step} spp per step, each GPU its own samples"),
                        "rays_per_sample": round(rays / max(1, total["samples"]), 3),
                        "nodes_per_ray": round((total["nodes_closest"] + total["nodes_shadow"]) / max(1, rays), 2),
                        "tri_tests_per_ray": round((total["tri_tests_closest"] + total["tri_tests_shadow"]) / max(1, rays), 3)},

@@ -347,12 +347,14 @@ int pt_trace_any_mode( PtScene* scene, uint32_t traversal, uint64_t n, const flo
                        const float* t_max, uint8_t* occluded,
                        uint32_t* nodes_visited, uint32_t* prim_tests );
 
-/* pt_trace_closest for callers that cannot allocate device memory (code under HIP graph capture, tight serving
- * loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments and results as
- * pt_trace_closest, but the rays and results are staged in an array that is part of the library's code object
- * (12 MiB per GPU, there until the process ends) instead of freshly allocated buffers: the call makes no hipMalloc
- * or hipFree.  At most PT_TRACE_STATIC_MAX_RAYS rays per call, more is PT_ERR_INVALID_ARG.  All scenes on one GPU
- * share that GPU's array, so calls that overlap in time on one GPU race; calls on different GPUs do not. */
+/* pt_trace_closest for callers that must not allocate device memory (tight serving loops, harnesses that forbid
+ * hipMalloc, a process whose memory is spoken for).  No counterpart in the reference.  Same arguments and results as
+ * pt_trace_closest - it always traverses in the reference's order, PT_TRAVERSAL_REFERENCE - but the rays and results are
+ * staged in an array that is part of the library's code object (12 MiB per GPU, there until the process ends) instead of
+ * freshly allocated buffers: the call makes no hipMalloc or hipFree.  It copies from and to the caller's host arrays
+ * and waits for the GPU before it returns, so it is not for use under stream capture.  At most
+ * PT_TRACE_STATIC_MAX_RAYS rays per call, more is PT_ERR_INVALID_ARG.  All scenes on one GPU share that GPU's array, so
+ * calls that overlap in time on one GPU race; calls on different GPUs do not. */
 #define PT_TRACE_STATIC_MAX_RAYS 262144u
 int pt_trace_closest_static( PtScene* scene, uint64_t n, const float* origins, const float* directions,
                              int32_t* prim, float* t, float* u, float* v,
@@ -366,8 +368,18 @@ int pt_film_device_ptr( PtScene* scene, void** device_ptr, uint64_t* bytes );
 /* Adds the films of `sources`, in the order given, to the film of `dst`, on dst's GPU: one host process that drives
  * several GPUs (one scene each) sums their films without staging them in host memory.  A source on another GPU is
  * read in place over xGMI (peer access; copied GPU to GPU first where the GPUs cannot map each other's memory).
- * The sources are left as they are.  No counterpart in the reference (it is single-process, single-device). */
+ * The sources are left as they are; each source's GPU is synchronised first, so a film rendered on a caller's stream is
+ * complete.  No counterpart in the reference (it is single-process, single-device). */
 int pt_merge_films( PtScene* dst, PtScene* const* sources, uint32_t num_sources );
+
+/* pt_merge_films with PT_MERGE_* flags. */
+enum
+{
+    PT_MERGE_STAGE_ALWAYS = 1u << 0 /* copy every source film into a buffer on dst's GPU before it is added, whether or not
+                                       dst's GPU can map it: the path taken between GPUs without peer access, selectable so
+                                       that it can be run (and timed) on any machine, one GPU included */
+};
+int pt_merge_films_ex( PtScene* dst, PtScene* const* sources, uint32_t num_sources, uint32_t flags );
 
 /* Clears the film and the counters. */
 int pt_clear_film( PtScene* scene );

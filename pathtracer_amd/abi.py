@@ -19,6 +19,7 @@ PT_TRAVERSAL_REFERENCE, PT_TRAVERSAL_ORDERED, PT_TRAVERSAL_WIDE = 0, 1, 2
 PT_TRACE_STATIC_MAX_RAYS = 262144
 PT_SCENE_NO_DIRECT_SUM, PT_SCENE_TOP_BREADTH_FIRST, PT_SCENE_NO_ORDERED_LAYOUT, PT_SCENE_NO_PARALLEL_SHADOWS = 1, 2, 4, 8
 PT_SCENE_NO_WIDE_LAYOUT = 16
+PT_MERGE_STAGE_ALWAYS = 1
 PT_K_RAYGEN, PT_K_EXTEND, PT_K_SHADE, PT_K_CONNECT, PT_K_FILM, PT_K_TONEMAP, PT_K_RESOLVE, PT_K_COUNT = range(8)
 KERNEL_NAMES = ("raygen", "extend", "shade", "connect", "film", "tonemap", "resolve")
 PTH_SPLIT_SAH, PTH_SPLIT_MIDDLE, PTH_SPLIT_EQUAL_COUNTS = 0, 1, 2

@@ -63,6 +63,7 @@ def lib():
         L.pt_download_film.argtypes = [C.c_void_p, C.c_void_p]
         L.pt_upload_film.argtypes = [C.c_void_p, C.c_void_p]
         L.pt_merge_films.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_uint32]
+        L.pt_merge_films_ex.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_uint32, C.c_uint32]
         L.pt_destroy_scene.argtypes = [C.c_void_p]
         L.pt_build_bvh.argtypes = [C.c_int32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64),
                                    C.POINTER(C.c_float)]
@@ -175,10 +176,11 @@ class DeviceScene:
             raise ValueError(f"film must be ({self.height}, {self.width}, 4)")
         _check(lib().pt_upload_film(self._h, film.ctypes.data))
 
-    def merge_films(self, others):
-        """Adds the films of the other DeviceScenes (same image size, any GPU) to this one's, on this one's GPU."""
+    def merge_films(self, others, stage_always=False):
+        """Adds the films of the other DeviceScenes (same image size, any GPU) to this one's, on this one's GPU.
+        stage_always: through a copy on this GPU (PT_MERGE_STAGE_ALWAYS), the path of GPUs without peer access."""
         handles = (C.c_void_p * len(others))(*[o._h for o in others])
-        _check(lib().pt_merge_films(self._h, handles, len(others)))
+        _check(lib().pt_merge_films_ex(self._h, handles, len(others), abi.PT_MERGE_STAGE_ALWAYS if stage_always else 0))
 
     def film_device_ptr(self):
         ptr, nbytes = C.c_void_p(), C.c_uint64()

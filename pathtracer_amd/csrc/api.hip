@@ -1114,8 +1114,10 @@ try
     if ( desc->device < 0 || desc->device >= deviceCount ) return Fail( PT_ERR_DEVICE, "device %d requested, %d GPU(s) visible", desc->device, deviceCount );
     HIP_TRY( hipSetDevice( desc->device ) );
     {
-        unsigned char* staging = nullptr; // set-up for pt_trace_closest_static: this GPU's address of the staging array
-        HIP_TRY( ScratchAddress( desc->device, &staging ) );
+        // set-up for pt_trace_closest_static: this GPU's address of the staging array.  Should the lookup fail, that entry
+        // point will say so when it is called; nothing else needs the array.
+        unsigned char* staging = nullptr;
+        if ( ScratchAddress( desc->device, &staging ) != hipSuccess ) (void)hipGetLastError();
     }
 
     std::unique_ptr< PtScene > owner( new PtScene ); // freed on every early return and if anything below throws
@@ -1392,46 +1394,55 @@ catch ( ... )
     return HostFailure( "pt_film_device_ptr" );
 }
 
-int pt_merge_films( PtScene* dst, PtScene* const* sources, uint32_t num_sources )
+int pt_merge_films_ex( PtScene* dst, PtScene* const* sources, uint32_t num_sources, uint32_t flags )
 try
 {
     if ( !dst || ( num_sources && !sources ) ) return Fail( PT_ERR_INVALID_ARG, "pt_merge_films: null argument" );
+    if ( flags & ~static_cast< uint32_t >( PT_MERGE_STAGE_ALWAYS ) ) return Fail( PT_ERR_INVALID_ARG, "pt_merge_films: unknown flags %u", flags );
     for ( uint32_t i = 0; i < num_sources; ++i )
     {
         const PtScene* src = sources[i];
         if ( !src || src == dst ) return Fail( PT_ERR_INVALID_ARG, "pt_merge_films: source %u is null or the destination itself", i );
         if ( src->width != dst->width || src->height != dst->height ) return Fail( PT_ERR_INVALID_ARG, "pt_merge_films: source %u is %d x %d, the destination %d x %d", i, src->width, src->height, dst->width, dst->height );
     }
+    // whatever happens below, the calling thread is left on the destination's GPU
+    struct OnDevice
+    {
+        int device;
+        ~OnDevice() { (void)hipSetDevice( device ); }
+    } restore{ dst->device };
     const LaunchCfg cfg{ dst->stream, dst->gridBlocks, dst->extendBlocks, dst->connectBlocks, false };
     const uint32_t pixels = static_cast< uint32_t >( dst->width ) * static_cast< uint32_t >( dst->height );
-    DeviceBuffer staging; // only for a source GPU whose memory this GPU cannot map
+    DeviceBuffer staging; // for a source GPU whose memory this GPU cannot map (or PT_MERGE_STAGE_ALWAYS)
     for ( uint32_t i = 0; i < num_sources; ++i ) // in the order given: the sum does not depend on timing
     {
         PtScene* src = sources[i];
         HIP_TRY( hipSetDevice( src->device ) );
-        HIP_TRY( hipStreamSynchronize( src->stream ) ); // its film is complete
+        HIP_TRY( hipDeviceSynchronize() ); // its film is complete, on whichever stream it was rendered (PtRenderParams::stream)
         HIP_TRY( hipSetDevice( dst->device ) );
         const float4* other = src->film.As< float4 >();
-        if ( src->device != dst->device )
+        bool staged = ( flags & PT_MERGE_STAGE_ALWAYS ) != 0;
+        if ( !staged && src->device != dst->device )
         {
             int mappable = 0;
             HIP_TRY( hipDeviceCanAccessPeer( &mappable, dst->device, src->device ) );
             if ( mappable )
             {
                 const hipError_t e = hipDeviceEnablePeerAccess( src->device, 0 );
-                if ( e == hipErrorPeerAccessAlreadyEnabled ) (void)hipGetLastError();
-                else if ( e != hipSuccess ) mappable = 0;
+                if ( e != hipSuccess ) (void)hipGetLastError(); // already enabled, or refused: either way not an error of this call
+                if ( e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled ) mappable = 0;
             }
-            if ( !mappable )
-            {
-                if ( !staging.ptr ) HIP_TRY( staging.Allocate( dst->film.bytes ) );
-                HIP_TRY( hipMemcpyPeerAsync( staging.ptr, dst->device, src->film.ptr, src->device, dst->film.bytes, dst->stream ) );
-                other = staging.As< float4 >();
-            }
+            staged = !mappable;
+        }
+        if ( staged )
+        {
+            if ( !staging.ptr ) HIP_TRY( staging.Allocate( dst->film.bytes ) );
+            HIP_TRY( hipMemcpyPeerAsync( staging.ptr, dst->device, src->film.ptr, src->device, dst->film.bytes, dst->stream ) );
+            other = staging.As< float4 >();
         }
         LaunchAddFilm( cfg, dst->film.As< float4 >(), other, pixels );
         HIP_TRY( hipGetLastError() );
-        if ( other == staging.As< float4 >() ) HIP_TRY( hipStreamSynchronize( dst->stream ) ); // before the next source overwrites it
+        if ( staged ) HIP_TRY( hipStreamSynchronize( dst->stream ) ); // before the next source overwrites the buffer
     }
     HIP_TRY( hipStreamSynchronize( dst->stream ) );
     dst->rendered = true;
@@ -1441,6 +1452,8 @@ catch ( ... )
 {
     return HostFailure( "pt_merge_films" );
 }
+
+int pt_merge_films( PtScene* dst, PtScene* const* sources, uint32_t num_sources ) { return pt_merge_films_ex( dst, sources, num_sources, 0u ); }
 
 int pt_download_film( PtScene* s, float* film_rgba )
 try
@@ -1526,7 +1539,7 @@ try
     if ( n == 0 ) return PT_OK;
     HIP_TRY( hipSetDevice( s->device ) );
     unsigned char* base = nullptr;
-    HIP_TRY( ScratchAddress( s->device, &base ) ); // found at pt_upload_scene; a table lookup here
+    HIP_TRY( ScratchAddress( s->device, &base ) ); // found at pt_upload_scene as a rule; a table lookup here
     float* dO       = reinterpret_cast< float* >( base );
     float* dD       = reinterpret_cast< float* >( base + kStaticRays * 12 );
     int32_t* dPrim  = reinterpret_cast< int32_t* >( base + kStaticRays * 24 );

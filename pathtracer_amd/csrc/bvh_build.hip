@@ -852,7 +852,8 @@ __global__ __launch_bounds__( 64 ) void SubtreeKernel( const float4* __restrict_
 }
 
 // Shapes in scene order; *notFinite is set if a bound is an infinity or a NaN (the sums above order floats as
-// integers, which has no place for a NaN).
+// integers, which has no place for a NaN), or if a centre - half the sum of two bounds, as the reference computes it
+// (src/bvh.cpp:213) - would overflow to one.
 __global__ void FillItemsKernel( const float* __restrict__ boxes, float4* __restrict__ items, uint32_t n, uint32_t* __restrict__ notFinite )
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -862,6 +863,7 @@ __global__ void FillItemsKernel( const float* __restrict__ boxes, float4* __rest
     items[2ull * i + 1] = float4{ b[3], b[4], b[5], 0.0f };
     bool finite = true;
     for ( int k = 0; k < 6; ++k ) finite = finite && fabsf( b[k] ) <= kFltMax;
+    for ( int k = 0; k < 3; ++k ) finite = finite && fabsf( b[k] + b[k + 3] ) <= kFltMax;
     if ( !finite ) atomicOr( notFinite, 1u );
 }
 
@@ -953,7 +955,7 @@ int Build( int32_t device, const float* boxes, uint64_t n64, PtBvhNode* nodesOut
     {
         uint32_t notFinite = 0;
         BVH_TRY( hipMemcpy( &notFinite, dCounters.p, 4, hipMemcpyDeviceToHost ) );
-        if ( notFinite ) return Fail( PT_ERR_INVALID_SCENE, "a box has a bound that is not finite" );
+        if ( notFinite ) return Fail( PT_ERR_INVALID_SCENE, "a box has a bound that is not finite, or bounds whose sum is not (pass --host-bvh to the command line program to build such a tree on the host)" );
     }
     BVH_TRY( hipMemsetAsync( dSeg.p, 0, 4ull * n, stream ) );
 

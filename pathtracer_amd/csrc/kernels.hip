@@ -1478,26 +1478,24 @@ void ExtendWideKernel( SceneView sv, PathBuffers pb, int bounce, uint32_t numPat
 // scene has one light with one sample, so a path has at most one record per bounce and its record holds
 // throughput * LDirect and the path id (ShadeKernel): an unoccluded record is added to the path's radiance
 // here (path_tracer.cpp:133-134) and ResolveKernel does not run.
-template < bool kDirectSum, bool kOrdered >
+template < bool kDirectSum >
 __global__ __launch_bounds__( kConnectBlock ) PT_CONNECT_OCCUPANCY void ConnectKernel( SceneView sv, PathBuffers pb, int bounce, uint64_t* stats )
 {
     UnitStream stream{ pb.cursors + 2 * bounce + 1, UnitCount( pb, bounce, kCountShadowRays, 0 ), pb.units, kUnitPaths * pb.shadowSlots, 0u };
-    const uint32_t end      = kOrdered ? sv.numOrderedNodes : sv.numNodes;
+    const uint32_t end      = sv.numNodes;
     const uint32_t entries  = pb.units * kUnitPaths;
-    const SceneBuffers sb   = MakeSceneBuffers< kOrdered >( sv );
+    const SceneBuffers sb   = MakeSceneBuffers< false >( sv );
     __shared__ float4 topLds[kLdsTopNodes > 0 ? 2 * kLdsTopNodes : 1];
-    const uint32_t topCount = kOrdered ? ( kLdsTopNodes / 2 < sv.numTopOrdered ? kLdsTopNodes / 2 : sv.numTopOrdered )
-                                       : ( kLdsTopNodes < sv.numTopNodes ? kLdsTopNodes : sv.numTopNodes );
+    const uint32_t topCount = kLdsTopNodes < sv.numTopNodes ? kLdsTopNodes : sv.numTopNodes;
     if ( kLdsTopNodes > 0 )
     {
-        for ( uint32_t i = threadIdx.x; i < ( kOrdered ? 4 : 2 ) * topCount; i += kConnectBlock ) topLds[i] = Load16( sb.nodes, 16u * i );
+        for ( uint32_t i = threadIdx.x; i < 2 * topCount; i += kConnectBlock ) topLds[i] = Load16( sb.nodes, 16u * i );
         __syncthreads();
     }
     uint32_t rec = kNoRay, node = end, leaf = kInnerNode;
     f3 o = F3( 0.0f, 0.0f, 0.0f ), d = o, inv = o;
     float tMax = 0.0f;
     bool nx = false, ny = false, nz = false, occluded = false;
-    uint32_t linkOffset = 32u; // kOrdered: byte offset of the ray's link in a node record
     uint32_t waveRays = 0, waveNodes = 0, waveTris = 0, waveSpheres = 0, waveSteps = 0; // whole-wave totals, wave-uniform
 
     for ( ;; )
@@ -1548,7 +1546,6 @@ __global__ __launch_bounds__( kConnectBlock ) PT_CONNECT_OCCUPANCY void ConnectK
                     tMax = dir.w;
                     inv  = F3( 1.0f / d.x, 1.0f / d.y, 1.0f / d.z ); // bvh.cpp:275-276
                     nx = inv.x < 0; ny = inv.y < 0; nz = inv.z < 0;
-                    if constexpr ( kOrdered ) linkOffset = LinkOffset( nx, ny, nz );
                     occluded = false;
                     node     = 0;
                 }
@@ -1593,54 +1590,25 @@ __global__ __launch_bounds__( kConnectBlock ) PT_CONNECT_OCCUPANCY void ConnectK
             waveSteps++;
             if ( go )
             {
-                if constexpr ( kOrdered )
+                float4 a, b;
+                if ( kLdsTopNodes > 0 && node < topCount )
                 {
-                    float4 a, b;
-                    uint32_t link;
-                    if ( kLdsTopNodes > 0 && node < topCount )
-                    {
-                        a    = LoadLds16( topLds + 4 * node );
-                        b    = LoadLds16( topLds + 4 * node + 1 );
-                        link = *reinterpret_cast< const uint32_t* >( reinterpret_cast< const char* >( topLds ) + 64u * node + linkOffset );
-                    }
-                    else
-                    {
-                        a    = Load16( sb.nodes, 64u * node );
-                        b    = Load16( sb.nodes, 64u * node + 16u );
-                        link = Load4( sb.nodes, 64u * node + linkOffset );
-                    }
-                    const uint32_t w0 = __float_as_uint( b.z ), w1 = __float_as_uint( b.w );
-                    const bool boxHit = RayBox( o, inv, nx, ny, nz, a, b, tMax );
-                    if ( boxHit && !( w1 & kLeafFlag ) )
-                        node = NearChild( w0, w1, linkOffset );
-                    else
-                    {
-                        node = link;
-                        if ( boxHit ) leaf = w0;
-                    }
+                    a = LoadLds16( topLds + 2 * node );
+                    b = LoadLds16( topLds + 2 * node + 1 );
                 }
                 else
                 {
-                    float4 a, b;
-                    if ( kLdsTopNodes > 0 && node < topCount )
-                    {
-                        a = LoadLds16( topLds + 2 * node );
-                        b = LoadLds16( topLds + 2 * node + 1 );
-                    }
-                    else
-                    {
-                        a = Load16( sb.nodes, 32u * node );
-                        b = Load16( sb.nodes, 32u * node + 16u );
-                    }
-                    const uint32_t link = __float_as_uint( b.z ), word = __float_as_uint( b.w );
-                    const bool boxHit = RayBox( o, inv, nx, ny, nz, a, b, tMax );
-                    if ( boxHit && !( link & kLeafFlag ) )
-                        node = word; // first child
-                    else
-                    {
-                        node = link & ~kLeafFlag;
-                        if ( boxHit ) leaf = word;
-                    }
+                    a = Load16( sb.nodes, 32u * node );
+                    b = Load16( sb.nodes, 32u * node + 16u );
+                }
+                const uint32_t link = __float_as_uint( b.z ), word = __float_as_uint( b.w );
+                const bool boxHit = RayBox( o, inv, nx, ny, nz, a, b, tMax );
+                if ( boxHit && !( link & kLeafFlag ) )
+                    node = word; // first child
+                else
+                {
+                    node = link & ~kLeafFlag;
+                    if ( boxHit ) leaf = word;
                 }
             }
         }
@@ -2419,7 +2387,7 @@ void TraversalOccupancy( bool spheres, int* extendBlocksPerCu, int* connectBlock
     const hipError_t rc = spheres ? hipOccupancyMaxActiveBlocksPerMultiprocessor( &e, ExtendKernel< true, true >, kTraverseBlock, 0 )
                                   : hipOccupancyMaxActiveBlocksPerMultiprocessor( &e, ExtendKernel< false, true >, kTriangleBlock, 0 );
     if ( rc != hipSuccess || e < 1 ) e = 2;
-    if ( hipOccupancyMaxActiveBlocksPerMultiprocessor( &c, ConnectKernel< false, false >, kConnectBlock, 0 ) != hipSuccess || c < 1 ) c = 4;
+    if ( hipOccupancyMaxActiveBlocksPerMultiprocessor( &c, ConnectKernel< false >, kConnectBlock, 0 ) != hipSuccess || c < 1 ) c = 4;
     *extendBlocksPerCu  = e;
     *connectBlocksPerCu = c;
 }
@@ -2485,9 +2453,10 @@ void LaunchShade( const LaunchCfg& cfg, const SceneView& sv, const RngParams& rn
                             sampleBegin, numPaths, stats );
 }
 
-// Shadow rays always run in the reference's order: an any-hit query gives the same answer in either order, and the
-// front-to-back order was measured slower for it (Sponza-class scene: 41.6 instead of 43.1 nodes per shadow ray, but
-// every step reads a third word and the LDS copy holds half as many records: +11 % per launch).
+// Over the binary tree shadow rays always run in the reference's order: an any-hit query gives the same answer in either
+// order, and the front-to-back order was measured slower for it (Sponza-class scene: 41.6 instead of 43.1 nodes per shadow
+// ray, but every step reads a third word and the LDS copy holds half as many records: +11 % per launch), so ConnectKernel
+// has no front-to-back instance.
 void LaunchConnect( const LaunchCfg& cfg, const SceneView& sv, const PathBuffers& pb, int bounce, uint64_t* stats )
 {
     if ( cfg.wideShadows )
@@ -2504,9 +2473,9 @@ void LaunchConnect( const LaunchCfg& cfg, const SceneView& sv, const PathBuffers
     else if ( cfg.ordered && sv.shadowNodes )
         hipLaunchKernelGGL( ( ConnectParallelKernel< false > ), grid, block, 0, cfg.stream, sv, pb, bounce, stats );
     else if ( pb.directSum )
-        hipLaunchKernelGGL( ( ConnectKernel< true, false > ), grid, block, 0, cfg.stream, sv, pb, bounce, stats );
+        hipLaunchKernelGGL( ( ConnectKernel< true > ), grid, block, 0, cfg.stream, sv, pb, bounce, stats );
     else
-        hipLaunchKernelGGL( ( ConnectKernel< false, false > ), grid, block, 0, cfg.stream, sv, pb, bounce, stats );
+        hipLaunchKernelGGL( ( ConnectKernel< false > ), grid, block, 0, cfg.stream, sv, pb, bounce, stats );
 }
 
 void LaunchResolve( const LaunchCfg& cfg, const SceneView& sv, const PathBuffers& pb, int bounce )

@@ -36,7 +36,7 @@ struct BvhResult
 
 // Builds the tree over `bounds` (one box per shape, in scene order) exactly as BVH::Build does
 // (src/bvh.cpp:204-228): same split decisions, same std::partition / std::nth_element calls, same
-// flattening.  Throws std::runtime_error if the recursion cannot make progress (all centroids equal).
+// flattening.  A range whose centroids are all equal is halved where it lies (the reference's recursion never returns from one, src/bvh.cpp:173-175).
 BvhResult BuildBvh( const std::vector< Aabb >& bounds, SplitMethod method );
 
 // A builder with the interface of pt_build_bvh (pt_api.h) that takes over the SAH trees of HostScene::BuildAccel,

@@ -32,7 +32,7 @@ struct Options
     std::string sceneFile, resourceDir, output, generate;
     int width = 0, height = 0, depth = -1, spp = 0, device = 0, triangles = 0;
     uint64_t seed = 0;
-    bool haveSeed = false, stats = false, hostTonemap = false, referenceOrder = false, hostBvh = false;
+    bool haveSeed = false, stats = false, hostTonemap = false, referenceOrder = false, binaryTree = false, hostBvh = false;
     std::vector< int > devices; // --devices: the GPUs that share a render; empty = the one of --device
 };
 
@@ -54,8 +54,10 @@ void Help()
                  "  --output FILE        override OutputImageFilename\n"
                  "  --generate atrium|knot|soup [--triangles N]   procedural scene instead of SCENE_FILE\n"
                  "  --stats              print ray and traversal counters after each render\n"
-                 "  --reference-order    visit the BVH in the reference's first-child-first order instead of front to back:\n"
-                 "                       same picture, traversal counters equal to the CPU path's, slower on large scenes\n"
+                 "  --reference-order    visit the BVH in the reference's first-child-first order instead of front to back over the\n"
+                 "                       eight-wide layout: same picture, traversal counters equal to the CPU path's, slower on\n"
+                 "                       large scenes\n"
+                 "  --binary-tree        front to back over the binary tree itself instead of the eight-wide layout (same picture)\n"
                  "  --host-bvh           build SAH trees on the host instead of the GPU (the same tree either way, node for\n"
                  "                       node; the other split methods are always built on the host)\n"
                  "  --host-tonemap       run the tonemap pass on the host with the C library's powf, as the reference\n"
@@ -112,6 +114,8 @@ bool ParseArgs( int argc, char** argv, Options& o )
             o.hostTonemap = true;
         else if ( a == "--reference-order" )
             o.referenceOrder = true;
+        else if ( a == "--binary-tree" )
+            o.binaryTree = true;
         else if ( a == "--host-bvh" )
             o.hostBvh = true;
         else if ( a == "--seed" && ( v = value() ) )
@@ -144,8 +148,9 @@ std::string DefaultResourceDir( const std::string& sceneFile )
 class PathTracer
 {
 public:
-    PathTracer( const std::vector< PtScene* >& gpuScenes, int width, int height, const PtCamera& camera, bool hostTonemap, bool ordered )
-        : m_scenes( gpuScenes ), m_width( width ), m_height( height ), m_camera( camera ), m_hostTonemap( hostTonemap ), m_ordered( ordered )
+    // renderFlags: PT_RENDER_* that choose the traversal (the same picture from each)
+    PathTracer( const std::vector< PtScene* >& gpuScenes, int width, int height, const PtCamera& camera, bool hostTonemap, uint32_t renderFlags )
+        : m_scenes( gpuScenes ), m_width( width ), m_height( height ), m_camera( camera ), m_hostTonemap( hostTonemap ), m_renderFlags( renderFlags )
     {
     }
 
@@ -162,14 +167,21 @@ public:
             const int base = samplesPerPixel / gpus, extra = samplesPerPixel % gpus;
             PtRenderParams params{};
             params.struct_size  = sizeof( params );
-            params.flags        = m_ordered ? PT_RENDER_ORDERED : 0u;
+            params.flags        = m_renderFlags;
             params.spp_total    = samplesPerPixel;
             params.sample_begin = g * base + std::min( g, extra );
             params.sample_end   = params.sample_begin + base + ( g < extra ? 1 : 0 );
             params.rng_mode     = PT_RNG_PHILOX;
             params.seed         = seed;
-            auto work = [this, g, params, &errors] {
-                if ( pt_render( m_scenes[g], &params ) != PT_OK ) errors[g] = pt_last_error(); // the message is per thread
+            auto work = [this, g, params, &errors]() mutable {
+                int rc = pt_render( m_scenes[g], &params );
+                if ( rc == PT_ERR_STATE && ( params.flags & PT_RENDER_WIDE ) )
+                {
+                    // a tree the eight-wide layout cannot express: front to back over the tree itself
+                    params.flags = ( params.flags & ~static_cast< uint32_t >( PT_RENDER_WIDE | PT_RENDER_WIDE_SHADOWS ) ) | PT_RENDER_ORDERED;
+                    rc           = pt_render( m_scenes[g], &params );
+                }
+                if ( rc != PT_OK ) errors[g] = pt_last_error(); // the message is per thread
             };
             if ( gpus == 1 ) work();
             else workers.emplace_back( work );
@@ -239,7 +251,8 @@ private:
     std::vector< PtScene* > m_scenes;
     int m_width, m_height;
     PtCamera m_camera;
-    bool m_hostTonemap, m_ordered;
+    bool m_hostTonemap;
+    uint32_t m_renderFlags;
 };
 
 } // namespace
@@ -279,7 +292,7 @@ int main( int argc, char** argv )
     {
         // the reference logs the failure and exits with status 0 (src/main.cpp:25-29)
         std::cout << "Could not load scene file '" << ( opt.generate.empty() ? opt.sceneFile : opt.generate ) << "': " << pth_last_error();
-        if ( *pt_last_error() ) std::cout << " (" << pt_last_error() << ")"; // the GPU tree builder's own words, if it was the one that failed
+        if ( *pt_last_error() ) std::cout << " (" << pt_last_error() << "; --host-bvh builds the tree on the host instead)"; // the GPU tree builder's own words, if it was the one that failed
         std::cout << std::endl;
         return 0;
     }
@@ -329,10 +342,12 @@ int main( int argc, char** argv )
     // Perform all the renderings ("SamplesPerPixel": [ 8, 32, ... ]), src/main.cpp:30-49
     for ( size_t it = 0; it < sppList.size(); ++it )
     {
-        // front to back unless asked otherwise - or the tree is so small that the traversal kernels' LDS copy holds it
-        // whole, where that order only adds its third load per node step and its second pass (same picture either way)
-        const bool ordered = !opt.referenceOrder && desc.num_nodes > 2400;
-        PathTracer pathTracer( gpuScenes, desc.image_width, desc.image_height, desc.camera, opt.hostTonemap, ordered );
+        // over the eight-wide layout (closest hits and shadow rays) unless asked otherwise - or the tree is so small that the
+        // binary-tree kernels' LDS copy holds it whole, where the reference's order is the fastest (same picture either way)
+        uint32_t renderFlags = 0;
+        if ( opt.binaryTree && !opt.referenceOrder ) renderFlags = PT_RENDER_ORDERED;
+        else if ( !opt.referenceOrder && desc.num_nodes > 2400 ) renderFlags = PT_RENDER_WIDE | PT_RENDER_WIDE_SHADOWS;
+        PathTracer pathTracer( gpuScenes, desc.image_width, desc.image_height, desc.camera, opt.hostTonemap, renderFlags );
         PtStats stats{};
         const uint64_t seed = opt.haveSeed ? opt.seed : ( static_cast< uint64_t >( entropy() ) << 32 | entropy() );
         if ( !pathTracer.Render( sppList[it], seed, &stats ) )

@@ -65,15 +65,18 @@ def sample_range(spp, rank, world_size):
 
 
 class PathTracer:
-    # A tree this small sits in the traversal kernels' LDS copy whole; the front-to-back order then only adds its
-    # third load per node step and its second pass (Cornell box: 71.6 against 66.9 ms of closest-hit traversal)
+    # A tree this small sits whole in the LDS copy the binary-tree kernels keep; the reference's order is then the fastest
+    # (Cornell box, closest-hit traversal of 256 samples per pixel: 66.7 ms, front to back 70.9, eight-wide layout 69.8)
     SMALL_TREE_NODES = 2400
 
-    def __init__(self, device=0, seed=0, tonemap=abi.PT_TONEMAP_UNCHARTED2, ordered=None):
+    def __init__(self, device=0, seed=0, tonemap=abi.PT_TONEMAP_UNCHARTED2, ordered=None, traversal=None):
         self.device = device
         self.seed = seed
         self.tonemap = tonemap
-        self.ordered = ordered      # front-to-back traversal: same picture, fewer node visits; None: unless the tree is small
+        # "reference", "ordered" (front to back over the binary tree) or "wide" (the eight-wide layout, shadow rays too): the
+        # same picture from each; None: "wide" unless the tree is small.  `ordered` is the older switch: True = "ordered",
+        # False = "reference".
+        self.traversal = traversal if traversal is not None else {None: None, True: "ordered", False: "reference"}[ordered]
         self.renderedImage = None   # tonemapped, what the reference keeps (src/path_tracer.cpp:210-221)
         self.linearImage = None     # the image before the tonemap pass, which the reference overwrites
         self.stats = None
@@ -96,8 +99,8 @@ class PathTracer:
         except ImportError:
             pass
         begin, end = sample_range(spp, rank, world)
-        ordered = self.ordered if self.ordered is not None else scene._desc.num_nodes > self.SMALL_TREE_NODES
-        dev.render(spp, begin, end, seed=self.seed, ordered=ordered)
+        traversal = self.traversal or ("wide" if scene._desc.num_nodes > self.SMALL_TREE_NODES else "reference")
+        dev.render(spp, begin, end, seed=self.seed, ordered=traversal != "reference", wide=traversal == "wide", wide_shadows=traversal == "wide")
         if world > 1:
             reduce_film(dev, self.device, dist, process_group)
             if rank != 0:

@@ -3,9 +3,13 @@
 // instruction occupies a CU (cycles per instruction per CU at full occupancy) - which tells whether the memory
 // pipeline charges a load by instruction, by active lane or by byte.
 //   hipcc --offload-arch=gfx950 -O3 -o gather gather.hip && ./gather
+// With arguments `width lanes footprint` it runs that one case (a warming launch, then the one that counts) and prints
+// the 64-byte lines the second launch touched: for a profiler pass that counts what left the L2 (FETCH_SIZE), see
+// profiles/calibrate_fetch_size.sh.
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #define CHECK( x ) do { hipError_t e = ( x ); if ( e != hipSuccess ) { std::printf( "%s: %s\n", #x, hipGetErrorString( e ) ); return 1; } } while ( 0 )
@@ -60,7 +64,7 @@ __global__ __launch_bounds__( 1024 ) void Gather( const void* base, uint32_t byt
     if ( acc == 0x12345678u ) out[0] = acc; // never true for the zero-filled buffer; keeps the loads alive
 }
 
-int main()
+int main( int argc, char** argv )
 {
     hipDeviceProp_t prop;
     CHECK( hipGetDeviceProperties( &prop, 0 ) );
@@ -77,6 +81,22 @@ int main()
     CHECK( hipEventCreate( &t0 ) );
     CHECK( hipEventCreate( &t1 ) );
     const int blocks = 2 * cus, loads = 2048;
+    if ( argc == 4 )
+    {
+        const int width = std::atoi( argv[1] ), lanes = std::atoi( argv[2] );
+        const uint32_t footprint = static_cast< uint32_t >( std::strtoul( argv[3], nullptr, 10 ) );
+        for ( int rep = 0; rep < 2; ++rep )
+        {
+            if ( width == 16 ) hipLaunchKernelGGL( Gather< 16 >, dim3( blocks ), dim3( 1024 ), 0, 0, buffer, footprint, loads, lanes, 1, out );
+            else if ( width == 8 ) hipLaunchKernelGGL( Gather< 8 >, dim3( blocks ), dim3( 1024 ), 0, 0, buffer, footprint, loads, lanes, 1, out );
+            else hipLaunchKernelGGL( Gather< 4 >, dim3( blocks ), dim3( 1024 ), 0, 0, buffer, footprint, loads, lanes, 1, out );
+            CHECK( hipDeviceSynchronize() );
+        }
+        // every load of an active lane touches one 64-byte line of its own choosing
+        std::printf( "width %d lanes %d footprint %u: %.0f loads of one 64-byte line each per launch\n", width, lanes, footprint,
+                     static_cast< double >( blocks ) * 16.0 * lanes * loads );
+        return 0;
+    }
     std::printf( "%-6s %-7s %-9s %-10s %12s %14s %12s\n", "width", "lanes", "share", "footprint", "ms", "cyc/instr/CU", "GB/s" );
     for ( uint32_t footprint : { 16u << 10, 2u << 20, 1u << 30 } )
         for ( int sharedBy : { 1, 2, 4 } )

@@ -2,13 +2,21 @@
 plus the kernel-trace duration statistics when <dir>/trace is there.  Writes <dir>/pmc_summary.json and prints
 a table.  usage: python summarize_pmc.py <dir>
 
-Derived per-dispatch figures: fabric_read_bytes = FETCH_SIZE (KiB) * 1024 * 2 -- on gfx950 FETCH_SIZE tallies
-the memory-side read requests at half their size; fabric_write_bytes = WRITE_SIZE (KiB) * 1024.  Both count
-requests that leave the L2, including those the Infinity Cache serves.  valu_utilization = SQ_ACTIVE_INST_VALU
+Derived per-dispatch figures: fabric_read_bytes = FETCH_SIZE (KiB) * 1024 * factor; fabric_write_bytes = WRITE_SIZE (KiB)
+* 1024.  Both count requests that leave the L2, including those the Infinity Cache serves.  The factor: on gfx950
+FETCH_SIZE tallies the 128-byte requests of a wide coalesced streaming read at 64 bytes (factor 2), but reports a
+gather of 64-byte lines - one line per lane, 4, 8 or 16 bytes of it used - as it is: 63.8 bytes per line touched over a
+1 GiB footprint (profiles/r03_fetch_size_calibration.txt, profiles/calibrate_fetch_size.sh).  The traversal and shading
+kernels gather (factor 1; the coalesced part of their traffic - rays in, state of a path - is then under-counted, which
+makes their figure a lower bound); the kernels that only stream take factor 2.  valu_utilization = SQ_ACTIVE_INST_VALU
 (wave instructions issued, summed over the chip) * 4 cycles per wave64 instruction / (GRBM_GUI_ACTIVE / 8 XCDs,
 the kernel's duration in cycles) / 1024 SIMDs: the share of the SIMDs' vector issue slots the kernel uses."""
 import csv, glob, json, os, sys
 from collections import defaultdict
+
+# kernels whose reads are wide coalesced streams; every other kernel's reads are taken to be gathers
+STREAMING = ("RaygenKernel", "FilmKernel", "TonemapKernel", "AddFilmKernel", "ResolveKernel", "FlagKernel", "SwapKernel", "ScanSumsKernel",
+             "ScanApplyKernel", "PartnerKernel", "FillItemsKernel", "vectorized_elementwise_kernel")
 
 root = sys.argv[1]
 traversal = sys.argv[2] if len(sys.argv) > 2 else None
@@ -33,7 +41,8 @@ for k in sorted(tot):
     n = max(len(v) for v in disp[k].values())
     d = {"dispatches": n, "per_dispatch": per}
     if "FETCH_SIZE" in per:
-        d["fabric_read_bytes"] = per["FETCH_SIZE"] * 1024 * 2
+        d["fetch_size_factor"] = 2 if any(name in k for name in STREAMING) else 1
+        d["fabric_read_bytes"] = per["FETCH_SIZE"] * 1024 * d["fetch_size_factor"]
     if "WRITE_SIZE" in per:
         d["fabric_write_bytes"] = per["WRITE_SIZE"] * 1024
     if "TCP_TOTAL_CACHE_ACCESSES_sum" in per and per["TCP_TOTAL_CACHE_ACCESSES_sum"] > 0:
@@ -59,12 +68,10 @@ for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_stats.csv"), recur
                                           "percent": float(r["Percentage"])}
 
 # what the counters belong to: bench.py uses a summary only beside the kernels it was collected with
-import hashlib
 repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-h = hashlib.sha256()
-for f in ("pathtracer_amd/csrc/kernels.hip", "pathtracer_amd/csrc/pt_device.h", "pathtracer_amd/csrc/pt_sincosf.h", "pathtracer_amd/csrc/pt_powf.h", "pathtracer_amd/csrc/pt_acosf.h"):
-    h.update(open(os.path.join(repo, f), "rb").read())
-out["_meta"] = {"kernel_sources": h.hexdigest()[:16], "traversal": traversal}
+sys.path.insert(0, repo)
+from bench import kernel_source_hash  # noqa: E402  (one list of sources, one hash)
+out["_meta"] = {"kernel_sources": kernel_source_hash(), "traversal": traversal}
 
 json.dump(out, open(os.path.join(root, "pmc_summary.json"), "w"), indent=1, sort_keys=True)
 for k, d in out.items():

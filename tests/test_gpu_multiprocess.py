@@ -6,6 +6,7 @@
   picture is equal up to the re-association of the per-rank partial sums.
 * bench.py as the driver launches it for N > 1 (python -m torch.distributed.run), rehearsed on GPU 0, in both
   scaling modes: one JSON line from rank 0, every sample of the frame rendered once.
+* reduce_film over RCCL with the one rank a one-GPU box allows: the in-place reduce on the library's device buffer.
 * pt_merge_films, what a single host process with several GPUs uses instead (pathTracer --devices): films of several
   scenes added on the device.
 """
@@ -72,6 +73,41 @@ def test_render_split_over_processes_on_one_gpu(world, tmp_path, scenes):
     assert linear.max() > 0.05
 
 
+def _nccl_single_rank(rank, port, out_path):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from pathtracer_amd import api
+    from pathtracer_amd.path_tracer import film_tensor, reduce_film
+    from pathtracer_amd.scene import SceneData
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    data = SceneData.load(os.path.join(ROOT, "tests", "golden", "cornell_scene.npz")).with_image(SIZE, SIZE)
+    with api.DeviceScene(data.to_desc()) as dev:
+        dev.render(SPP, seed=SEED)
+        before = dev.download_film()
+        assert film_tensor(dev, 0).is_cuda
+        reduce_film(dev, 0, dist)                       # RCCL reduce, in place on the library's own device buffer
+        after = dev.download_film()
+        linear, _, _ = dev.readback()
+    np.savez(out_path, before=before, after=after, linear=linear)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_reduce_film_over_rccl_in_place(tmp_path):
+    """reduce_film's nccl branch - one RCCL reduce on the film's device memory, wrapped as a tensor without a copy - with
+    the one rank a one-GPU box allows: the film comes back as it was, and the picture can still be read."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "nccl.npz")
+    mp.spawn(_nccl_single_rank, args=(free_port(), out), nprocs=1, join=True)
+    got = np.load(out)
+    assert_bits_equal(got["after"], got["before"], "film after a one-rank reduce")
+    assert (got["after"][..., 3] == SPP).all() and got["linear"].max() > 0.05
+
+
 @pytest.mark.parametrize("scaling", ["weak", "strong"])
 def test_bench_launched_with_two_ranks(scaling):
     width, height, spp, steps, warmup = 64, 36, 4, 2, 1
@@ -85,7 +121,7 @@ def test_bench_launched_with_two_ranks(scaling):
     assert len(lines) == 1, r.stdout                                    # rank 0 alone prints
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["steps"] == steps and line["scaling"] == scaling and line["value"] > 0
-    frame_spp = spp * steps * (2 if scaling == "weak" else 1)
+    frame_spp = spp * steps * 2        # either way a rank renders `spp` samples per step; strong: as shares of one frame
     assert line["config"]["spp_rendered"] == frame_spp
     assert round(line["msamples_per_s"] * line["ms_per_step"] * steps * 1e3) == pytest.approx(width * height * frame_spp, rel=1e-3)
 
@@ -100,9 +136,15 @@ def test_merge_films_on_the_device(scenes):
         for dev, (begin, end) in zip((a, b, c), ((0, 4), (4, 7), (7, 9))):
             dev.render(9, begin, end, seed=5, ordered=True)
         want = (a.download_film() + b.download_film()) + c.download_film()
+        first = a.download_film()
         a.merge_films([b, c])
         assert_bits_equal(a.download_film(), want, "films added on the device")
         assert (want[..., 3] == 9).all()
+        # the path of GPUs that cannot map each other's memory: every source through a copy on the destination's GPU
+        a.upload_film(first)
+        a.merge_films([b, c], stage_always=True)
+        assert_bits_equal(a.download_film(), want, "films added through the staging copy")
+        assert_bits_equal((first + b.download_film()) + c.download_film(), want, "sources untouched")
         merged, _, _ = a.readback()
         a.render(9, seed=5, ordered=True)
         whole, _, _ = a.readback()

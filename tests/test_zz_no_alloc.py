@@ -34,7 +34,11 @@ def test_static_staging_equals_allocating_entry_point(scenes):
         same(first, dev.trace_closest(o, d), "full batch")
         assert (first["prim"] >= 0).mean() > 0.3
         o2, d2 = rays(cornell, 1000, 2)                                # smaller: stale results lie behind it
-        same(dev.trace_closest_static(o2, d2), dev.trace_closest(o2, d2), "second, smaller batch")
+        import torch
+        free_before = torch.cuda.mem_get_info(0)[0]
+        second = dev.trace_closest_static(o2, d2)
+        assert torch.cuda.mem_get_info(0)[0] == free_before, "the static entry point changed the GPU's free memory"
+        same(second, dev.trace_closest(o2, d2), "second, smaller batch")
         o3, d3 = rays(mixed, 5000, 3)                                  # another scene on the same GPU, same array
         same(other.trace_closest_static(o3, d3), other.trace_closest(o3, d3), "second scene")
         same(dev.trace_closest_static(o2, d2), dev.trace_closest(o2, d2), "first scene again")
