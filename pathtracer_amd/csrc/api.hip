@@ -394,6 +394,15 @@ int Upload( PtScene* s, const PtSceneDesc* d, const std::vector< uint32_t >& esc
 {
     const uint32_t N = static_cast< uint32_t >( d->num_nodes );
     const uint64_t P = d->num_prims;
+    // PTAMD_UPLOAD_TIMING in the environment: the wall time of each part of the upload on stderr
+    const bool timing = std::getenv( "PTAMD_UPLOAD_TIMING" ) != nullptr;
+    auto phaseStart   = std::chrono::steady_clock::now();
+    auto phase = [&]( const char* name ) {
+        if ( !timing ) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf( stderr, "[pt_upload_scene] %-28s %8.1f ms\n", name, std::chrono::duration< double, std::milli >( now - phaseStart ).count() );
+        phaseStart = now;
+    };
 
     // Device order of the nodes: the top of the tree first (contiguous: the traversal kernels copy its beginning
     // into LDS), sibling pairs in the order of their parents' box area, everything below in the reference's pre-order.  The traversal follows stored
@@ -482,6 +491,7 @@ int Upload( PtScene* s, const PtSceneDesc* d, const std::vector< uint32_t >& esc
     } );
     HIP_TRY( s->nodes.Upload( nodes.get(), 32ull * N ) );
     nodes.reset();
+    phase( "reference-order nodes" );
 
     // Second layout, for front-to-back traversal (kernels.hip, TraceClosestOrdered): 64-byte records, the root at 0,
     // record 1 unused, then sibling pairs at even indices - the top of the tree in the same order as above, below it
@@ -561,6 +571,7 @@ int Upload( PtScene* s, const PtSceneDesc* d, const std::vector< uint32_t >& esc
         } );
         HIP_TRY( s->orderedNodes.Upload( rec.get(), 64ull * numOrdered ) );
     }
+    phase( "front-to-back nodes" );
 
     // Third layout, for the shadow rays of a scene whose one light is directional (kernels.hip, ConnectParallelKernel):
     // every such ray has the light's direction, so seen along it a node is a rectangle, and the ray can only enter the
@@ -771,7 +782,8 @@ int Upload( PtScene* s, const PtSceneDesc* d, const std::vector< uint32_t >& esc
         }
     }
 
-    // 112 bytes of attributes in a 128-byte slot: one L2 line per record
+    phase( "directional-shadow nodes" );
+    // 100 bytes of attributes in a 128-byte slot: two 64-byte lines per record
     std::unique_ptr< float[] > prims( new float[16ull * P] ), shade( new float[32ull * P] );
     ParallelFor( P, [&]( uint64_t begin, uint64_t end ) {
     for ( uint64_t i = begin; i < end; ++i )
@@ -828,6 +840,7 @@ int Upload( PtScene* s, const PtSceneDesc* d, const std::vector< uint32_t >& esc
     HIP_TRY( s->prims.Upload( prims.get(), 64ull * P ) );
     HIP_TRY( s->triShade.Upload( shade.get(), 128ull * P ) );
     shade.reset();
+    phase( "primitive records" );
 
     // Fourth layout (wide_bvh.h): the tree collapsed to eight children per node, and the primitive records once more
     // in that tree's order with the reference's index in place of the tag.  A tree it cannot express (a bound that is
@@ -860,6 +873,7 @@ int Upload( PtScene* s, const PtSceneDesc* d, const std::vector< uint32_t >& esc
         }
     }
     prims.reset();
+    phase( "wide nodes and primitives" );
 
     std::vector< float > spheres( 24ull * d->num_spheres, 0.0f );
     for ( uint64_t i = 0; i < d->num_spheres; ++i )
@@ -988,6 +1002,7 @@ int Upload( PtScene* s, const PtSceneDesc* d, const std::vector< uint32_t >& esc
     HIP_TRY( hipMemset( s->stats.ptr, 0, ST_COUNT * 8 ) );
     // per bounce: the two unit cursors of the traversal kernels and the length of the redo queue
     HIP_TRY( s->cursors.Allocate( 3 * 4 * static_cast< size_t >( s->maxDepth > 0 ? s->maxDepth : 1 ) ) );
+    phase( "materials, textures, film" );
     return PT_OK;
 }
 

@@ -23,11 +23,11 @@ def measure(name, desc, spp, repeats=3, mode="ordered", flags=0):
     t_upload = time.time()
     with api.DeviceScene(desc) as dev:
         t_upload = time.time() - t_upload
-        dev.render(min(spp, 2), seed=1, ordered=ordered, wide=wide)  # warm-up: allocations, code upload
+        dev.render(min(spp, 2), seed=1, ordered=ordered, wide=wide, wide_shadows=wide)  # warm-up: allocations, code upload
         dev.readback()
         best = None
         for r in range(repeats):
-            dev.render(spp, seed=r, ordered=ordered, wide=wide, profile=True)
+            dev.render(spp, seed=r, ordered=ordered, wide=wide, wide_shadows=wide, profile=True)
             _, _, st = dev.readback()
             if best is None or st.render_ms < best.render_ms:
                 best = st

@@ -1,5 +1,5 @@
 """Renders one of the procedural configurations once, for the profiler.
-usage: python3 profiles/render_config.py soup|knot|atrium [--triangles N] [--spp N] [--width W --height H] [--depth D]"""
+usage: python3 profiles/render_config.py soup|knot|atrium|cornell [--traversal wide|ordered|reference] [--triangles N] [--spp N] [--width W --height H] [--depth D]"""
 import argparse
 import json
 import os
@@ -11,7 +11,7 @@ sys.path.insert(0, ROOT)
 from pathtracer_amd import api, host  # noqa: E402
 
 p = argparse.ArgumentParser()
-p.add_argument("scene", choices=["soup", "knot", "atrium"])
+p.add_argument("scene", choices=["soup", "knot", "atrium", "cornell"])
 p.add_argument("--triangles", type=int, default=0)
 p.add_argument("--spp", type=int, default=4)
 p.add_argument("--width", type=int, default=0)
@@ -20,6 +20,16 @@ p.add_argument("--depth", type=int, default=-1)
 p.add_argument("--traversal", choices=("wide", "ordered", "reference"), default="ordered")
 a = p.parse_args()
 
+if a.scene == "cornell":
+    # configs[1]: the Cornell box of the golden fixtures at 1024 x 1024 (small tree: the traversal flags change nothing but the layout read)
+    from pathtracer_amd.scene import SceneData  # noqa: E402
+    sd = SceneData.load(os.path.join(ROOT, "tests", "golden", "cornell_scene.npz")).with_image(a.width or 1024, a.height or 1024)
+    with api.DeviceScene(sd.to_desc()) as dev:
+        dev.render(a.spp, seed=0, ordered=a.traversal != "reference", wide=a.traversal == "wide", wide_shadows=a.traversal == "wide")
+        _, _, st = dev.readback()
+        rays = st.rays_closest + st.rays_shadow
+        print(json.dumps({"scene": a.scene, "spp": a.spp, "rays": int(rays), "render_ms": st.render_ms, "mrays_per_s": rays / st.render_ms * 1e-3}))
+    sys.exit(0)
 if a.scene == "soup":
     hs = host.HostScene.soup(seed=3, triangles=a.triangles or 20_000_000, edge=0.01, skybox_size=1024)
 elif a.scene == "knot":
@@ -32,7 +42,7 @@ with hs:
     if a.depth >= 0:
         hs.set_max_depth(a.depth)
     with api.DeviceScene(hs.desc()) as dev:
-        dev.render(a.spp, seed=0, ordered=a.traversal != "reference", wide=a.traversal == "wide")
+        dev.render(a.spp, seed=0, ordered=a.traversal != "reference", wide=a.traversal == "wide", wide_shadows=a.traversal == "wide")
         _, _, st = dev.readback()
         rays = st.rays_closest + st.rays_shadow
         print(json.dumps({"scene": a.scene, "spp": a.spp, "rays": int(rays), "render_ms": st.render_ms,
