@@ -42,6 +42,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
 # everything that decides what the render kernels execute and what they read: the kernels, and the code that lays the scene out for them
 KERNEL_SOURCES = ("pathtracer_amd/csrc/kernels.hip", "pathtracer_amd/csrc/api.hip", "pathtracer_amd/csrc/wide_bvh.hip", "pathtracer_amd/csrc/wide_bvh.h",
+                  "pathtracer_amd/csrc/layout_build.hip", "pathtracer_amd/csrc/layout_build.h",
                   "pathtracer_amd/csrc/pt_device.h", "pathtracer_amd/csrc/pt_sincosf.h", "pathtracer_amd/csrc/pt_powf.h", "pathtracer_amd/csrc/pt_acosf.h",
                   "include/pt_api.h")
 

@@ -156,6 +156,9 @@ enum
     PT_SCENE_NO_ORDERED_LAYOUT = 1u << 2, /* do not build the second node layout that PT_RENDER_ORDERED and
                                             PT_TRAVERSAL_ORDERED need (64 bytes of device memory per node); those
                                             then fail with PT_ERR_STATE                                               */
+    PT_SCENE_HOST_LAYOUTS = 1u << 5,      /* write the node and primitive records on the host and copy them over,
+                                            instead of copying the description and writing them with kernels: the
+                                            same bytes, slower for large scenes; kept as the checker of the kernels    */
     PT_SCENE_NO_WIDE_LAYOUT = 1u << 4     /* do not build the eight-wide node layout that PT_RENDER_WIDE and
                                             PT_TRAVERSAL_WIDE need (about 25 bytes per node of the tree and a second
                                             copy of the 64-byte primitive records); those then fail with PT_ERR_STATE   */
@@ -359,6 +362,21 @@ int pt_trace_any_mode( PtScene* scene, uint32_t traversal, uint64_t n, const flo
 int pt_trace_closest_static( PtScene* scene, uint64_t n, const float* origins, const float* directions,
                              int32_t* prim, float* t, float* u, float* v,
                              uint32_t* nodes_visited, uint32_t* prim_tests );
+
+/* Copies one of the scene's record arrays from the GPU to `dst` (at most `capacity` bytes) and reports its size: for
+ * tests that compare the records the upload's kernels wrote with the ones its host loops write (PT_SCENE_HOST_LAYOUTS).
+ * dst may be NULL to ask for the size alone.  No counterpart in the reference. */
+enum
+{
+    PT_LAYOUT_REFERENCE_NODES = 0, /* 32-byte records, reference order of visits                    */
+    PT_LAYOUT_ORDERED_NODES   = 1, /* 64-byte records with a link per octant                        */
+    PT_LAYOUT_PRIMS           = 2, /* 64-byte intersection records                                  */
+    PT_LAYOUT_ATTRIBUTES      = 3, /* 128-byte attribute records                                    */
+    PT_LAYOUT_WIDE_NODES      = 4, /* 80-byte nodes of up to eight children                         */
+    PT_LAYOUT_WIDE_PRIMS      = 5, /* intersection records in the wide layout's order               */
+    PT_LAYOUT_SHADOW_NODES    = 6  /* 16-byte light-space records (one directional light)           */
+};
+int pt_read_layout( PtScene* scene, uint32_t which, void* dst, uint64_t capacity, uint64_t* bytes );
 
 /* The film of this scene on its GPU: image_width * image_height float4 (sum r, sum g, sum b, sample
  * count), for a host that merges the films of several GPUs with one RCCL reduce.  No counterpart in the

@@ -60,6 +60,7 @@ def lib():
         L.pt_trace_any_mode.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64] + [C.c_void_p] * 6
         L.pt_film_device_ptr.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
         L.pt_clear_film.argtypes = [C.c_void_p]
+        L.pt_read_layout.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
         L.pt_download_film.argtypes = [C.c_void_p, C.c_void_p]
         L.pt_upload_film.argtypes = [C.c_void_p, C.c_void_p]
         L.pt_merge_films.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_uint32]
@@ -181,6 +182,15 @@ class DeviceScene:
         stage_always: through a copy on this GPU (PT_MERGE_STAGE_ALWAYS), the path of GPUs without peer access."""
         handles = (C.c_void_p * len(others))(*[o._h for o in others])
         _check(lib().pt_merge_films_ex(self._h, handles, len(others), abi.PT_MERGE_STAGE_ALWAYS if stage_always else 0))
+
+    def read_layout(self, which):
+        """One of the scene's record arrays (abi.PT_LAYOUT_*) as bytes, copied from the GPU."""
+        nbytes = C.c_uint64()
+        _check(lib().pt_read_layout(self._h, which, None, 0, C.byref(nbytes)))
+        out = np.zeros(nbytes.value, np.uint8)
+        if nbytes.value:
+            _check(lib().pt_read_layout(self._h, which, out.ctypes.data, nbytes.value, C.byref(nbytes)))
+        return out
 
     def film_device_ptr(self):
         ptr, nbytes = C.c_void_p(), C.c_uint64()

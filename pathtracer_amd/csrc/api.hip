@@ -1,6 +1,7 @@
 // C-ABI of the path-tracing core (include/pt_api.h): scene validation and upload, the render loop that
 // sequences the wavefront kernels, readback, batch ray queries.
 #include "pt_api.h"
+#include "layout_build.h"
 #include "pt_device.h"
 #include "wide_bvh.h"
 
@@ -409,7 +410,10 @@ int Upload( PtScene* s, const PtSceneDesc* d, const std::vector< uint32_t >& esc
     // links, so the visit sequence is the reference's whatever the order in memory.
     uint32_t top = d->top_nodes ? d->top_nodes : kTopNodes;
     if ( top > N ) top = N;
-    std::vector< uint32_t > place( N + 1, 0xFFFFFFFFu ); // reference index -> device index
+    // The records are written on the device from the description as it is (layout_build.h); PT_SCENE_HOST_LAYOUTS keeps
+    // the host loops below, which produce the same bytes
+    const bool hostLayouts = ( d->flags & PT_SCENE_HOST_LAYOUTS ) != 0;
+    std::vector< uint32_t > place; // reference index -> device index (host path)
     std::vector< uint32_t > bfs; // the top of the tree: the root, then sibling pairs
     {
         bfs.reserve( top );
@@ -445,13 +449,25 @@ int Upload( PtScene* s, const PtSceneDesc* d, const std::vector< uint32_t >& esc
             bfs.push_back( bfs[head] + 1 );
             bfs.push_back( static_cast< uint32_t >( n.offset ) );
         }
-        uint32_t next = 0;
-        for ( uint32_t i : bfs ) place[i] = next++;
-        for ( uint32_t i = 0; i < N; ++i )
-            if ( place[i] == 0xFFFFFFFFu ) place[i] = next++;
-        place[N] = N; // the end of the traversal
+        if ( hostLayouts )
+        {
+            place.assign( N + 1, 0xFFFFFFFFu );
+            uint32_t next = 0;
+            for ( uint32_t i : bfs ) place[i] = next++;
+            for ( uint32_t i = 0; i < N; ++i )
+                if ( place[i] == 0xFFFFFFFFu ) place[i] = next++;
+            place[N] = N; // the end of the traversal
+        }
         s->topNodes = static_cast< uint32_t >( bfs.size() );
     }
+    // the top of the tree by reference index, for the searches below and on the device
+    std::vector< std::pair< uint32_t, uint32_t > > topByIndex( bfs.size() ); // (reference index, position in the top)
+    for ( uint32_t k = 0; k < bfs.size(); ++k ) topByIndex[k] = { bfs[k], k };
+    std::sort( topByIndex.begin(), topByIndex.end() );
+    auto inTop = [&]( uint32_t i ) {
+        const auto it = std::lower_bound( topByIndex.begin(), topByIndex.end(), std::make_pair( i, 0u ) );
+        return it != topByIndex.end() && it->first == i;
+    };
 
     // which subtrees hold a sphere (the front-to-back layouts enter their boxes whatever has been found, see kernels.hip);
     // children lie behind their parent in the reference's pre-order, so one backward pass does it
@@ -469,6 +485,49 @@ int Upload( PtScene* s, const PtSceneDesc* d, const std::vector< uint32_t >& esc
         }
     }
 
+    // the description on the device, for the kernels that write the records; released when the upload returns
+    DeviceBuffer rawNodes, rawEscape, rawPrims, rawTriangles, rawMeshes, rawVertices, rawNormals, rawTangents, rawUvs, rawSpheres, rawSphereBelow;
+    LayoutInputs in;
+    if ( !hostLayouts )
+    {
+        HIP_TRY( rawNodes.Upload( d->nodes, 32ull * N ) );
+        HIP_TRY( rawEscape.Upload( escape.data(), 4ull * N ) );
+        HIP_TRY( rawPrims.Upload( d->prims, sizeof( PtPrim ) * P ) );
+        HIP_TRY( rawTriangles.Upload( d->triangles, sizeof( PtTriangle ) * d->num_triangles ) );
+        HIP_TRY( rawMeshes.Upload( d->meshes, sizeof( PtMesh ) * d->num_meshes ) );
+        HIP_TRY( rawVertices.Upload( d->vertices, 12ull * d->num_vertices ) );
+        HIP_TRY( rawNormals.Upload( d->normals, 12ull * d->num_vertices ) );
+        HIP_TRY( rawTangents.Upload( d->tangents, 12ull * d->num_vertices ) );
+        HIP_TRY( rawUvs.Upload( d->uvs, 8ull * d->num_vertices ) );
+        HIP_TRY( rawSpheres.Upload( d->spheres, sizeof( PtSphere ) * d->num_spheres ) );
+        if ( !sphereBelow.empty() ) HIP_TRY( rawSphereBelow.Upload( sphereBelow.data(), N ) );
+        in.nodes = rawNodes.As< PtBvhNode >();       in.numNodes = N;
+        in.escape = rawEscape.As< uint32_t >();
+        in.prims = rawPrims.As< PtPrim >();          in.numPrims = P;
+        in.triangles = rawTriangles.As< PtTriangle >();
+        in.meshes = rawMeshes.As< PtMesh >();
+        in.vertices = rawVertices.As< float >();     in.normals = rawNormals.As< float >();
+        in.tangents = rawTangents.As< float >();     in.uvs = rawUvs.As< float >();
+        in.spheres = rawSpheres.As< PtSphere >();
+        in.sphereBelow = rawSphereBelow.As< uint8_t >();
+        phase( "description to the device" );
+
+        std::vector< uint32_t > topSorted( bfs.size() ), topRank( bfs.size() );
+        for ( size_t k = 0; k < bfs.size(); ++k )
+        {
+            topSorted[k] = topByIndex[k].first;
+            topRank[k]   = topByIndex[k].second;
+        }
+        DeviceBuffer dTopSorted, dTopRank;
+        HIP_TRY( dTopSorted.Upload( topSorted.data(), 4 * topSorted.size() ) );
+        HIP_TRY( dTopRank.Upload( topRank.data(), 4 * topRank.size() ) );
+        HIP_TRY( s->nodes.Allocate( 32ull * N ) );
+        BuildReferenceNodes( nullptr, in, dTopSorted.As< uint32_t >(), dTopRank.As< uint32_t >(), static_cast< uint32_t >( bfs.size() ), s->nodes.As< float4 >() );
+        HIP_TRY( hipGetLastError() );
+        HIP_TRY( hipDeviceSynchronize() ); // the two small buffers go out of scope here
+    }
+    else
+    {
     std::unique_ptr< float[] > nodes( new float[8ull * N] ); // every word is written below
     ParallelFor( N, [&]( uint64_t begin, uint64_t end ) {
         for ( uint64_t i = begin; i < end; ++i )
@@ -490,7 +549,7 @@ int Upload( PtScene* s, const PtSceneDesc* d, const std::vector< uint32_t >& esc
         }
     } );
     HIP_TRY( s->nodes.Upload( nodes.get(), 32ull * N ) );
-    nodes.reset();
+    }
     phase( "reference-order nodes" );
 
     // Second layout, for front-to-back traversal (kernels.hip, TraceClosestOrdered): 64-byte records, the root at 0,
@@ -498,7 +557,38 @@ int Upload( PtScene* s, const PtSceneDesc* d, const std::vector< uint32_t >& esc
     // every pair followed by the first child's subtree, then the second child's.  Each record carries, per octant of
     // ray directions, the node that follows its subtree when every inner node's near child is visited first.
     uint32_t numOrdered = 0, topOrdered = 0;
-    if ( !( d->flags & PT_SCENE_NO_ORDERED_LAYOUT ) )
+    if ( !( d->flags & PT_SCENE_NO_ORDERED_LAYOUT ) && !hostLayouts )
+    {
+        // the inner nodes of the top whose children lie below it, in ascending order: each starts a run of pairs, one per
+        // inner node of its subtree (a subtree of n nodes has ( n - 1 ) / 2 of them)
+        std::vector< uint32_t > roots;
+        for ( const auto& t : topByIndex )
+            if ( d->nodes[t.first].num_shapes == 0 && !inTop( t.first + 1 ) ) roots.push_back( t.first );
+        topOrdered = static_cast< uint32_t >( bfs.size() ) + 1u;
+        std::vector< uint32_t > rootBase( roots.size() );
+        uint32_t next = topOrdered;
+        for ( size_t j = 0; j < roots.size(); ++j )
+        {
+            rootBase[j] = next;
+            next += escape[roots[j]] - roots[j] - 1u; // two records per inner node
+        }
+        numOrdered = next; // N + 1
+        DeviceBuffer dTopOrder, dRoots, dRootBase, dAt, dParent, dInnerPrefix, dBlockSums;
+        HIP_TRY( dTopOrder.Upload( bfs.data(), 4 * bfs.size() ) );
+        HIP_TRY( dRoots.Upload( roots.data(), 4 * roots.size() ) );
+        HIP_TRY( dRootBase.Upload( rootBase.data(), 4 * rootBase.size() ) );
+        HIP_TRY( dAt.Allocate( 4ull * N ) );
+        HIP_TRY( dParent.Allocate( 4ull * N ) );
+        HIP_TRY( dInnerPrefix.Allocate( 4ull * ( N + 1 ) ) );
+        HIP_TRY( dBlockSums.Allocate( 4ull * ( LayoutScanBlocks( N ) + 1 ) ) );
+        HIP_TRY( s->orderedNodes.Allocate( 64ull * numOrdered ) );
+        BuildOrderedNodes( nullptr, in, dTopOrder.As< uint32_t >(), static_cast< uint32_t >( bfs.size() ), dRoots.As< uint32_t >(), dRootBase.As< uint32_t >(),
+                           static_cast< uint32_t >( roots.size() ), numOrdered, dAt.As< uint32_t >(), dParent.As< uint32_t >(), dInnerPrefix.As< uint32_t >(),
+                           dBlockSums.As< uint32_t >(), s->orderedNodes.As< uint4 >() );
+        HIP_TRY( hipGetLastError() );
+        HIP_TRY( hipDeviceSynchronize() );
+    }
+    else if ( !( d->flags & PT_SCENE_NO_ORDERED_LAYOUT ) )
     {
         const uint32_t unset = 0xFFFFFFFFu;
         std::vector< uint32_t > at( N, unset ); // reference index -> record
@@ -784,7 +874,18 @@ int Upload( PtScene* s, const PtSceneDesc* d, const std::vector< uint32_t >& esc
 
     phase( "directional-shadow nodes" );
     // 100 bytes of attributes in a 128-byte slot: two 64-byte lines per record
-    std::unique_ptr< float[] > prims( new float[16ull * P] ), shade( new float[32ull * P] );
+    std::unique_ptr< float[] > prims, shade;
+    if ( !hostLayouts )
+    {
+        HIP_TRY( s->prims.Allocate( 64ull * P ) );
+        HIP_TRY( s->triShade.Allocate( 128ull * P ) );
+        BuildPrimRecords( nullptr, in, s->prims.As< float4 >(), s->triShade.As< float4 >() );
+        HIP_TRY( hipGetLastError() );
+    }
+    else
+    {
+    prims.reset( new float[16ull * P] );
+    shade.reset( new float[32ull * P] );
     ParallelFor( P, [&]( uint64_t begin, uint64_t end ) {
     for ( uint64_t i = begin; i < end; ++i )
     {
@@ -840,6 +941,7 @@ int Upload( PtScene* s, const PtSceneDesc* d, const std::vector< uint32_t >& esc
     HIP_TRY( s->prims.Upload( prims.get(), 64ull * P ) );
     HIP_TRY( s->triShade.Upload( shade.get(), 128ull * P ) );
     shade.reset();
+    }
     phase( "primitive records" );
 
     // Fourth layout (wide_bvh.h): the tree collapsed to eight children per node, and the primitive records once more
@@ -855,6 +957,17 @@ int Upload( PtScene* s, const PtSceneDesc* d, const std::vector< uint32_t >& esc
             wideDepth = wide.depth;
             HIP_TRY( s->wideNodes.Upload( wide.nodes.data(), wide.nodes.size() * 4 ) );
             std::vector< uint32_t >().swap( wide.nodes );
+            if ( !hostLayouts )
+            {
+                DeviceBuffer dOrder;
+                HIP_TRY( dOrder.Upload( wide.primOrder.data(), 4ull * P ) );
+                HIP_TRY( s->widePrims.Allocate( 64ull * P ) );
+                GatherWidePrims( nullptr, in, s->prims.As< float4 >(), dOrder.As< uint32_t >(), s->widePrims.As< float4 >() );
+                HIP_TRY( hipGetLastError() );
+                HIP_TRY( hipDeviceSynchronize() );
+            }
+            else
+            {
             std::unique_ptr< float[] > ordered( new float[16ull * P] );
             ParallelFor( P, [&]( uint64_t begin, uint64_t end ) {
                 for ( uint64_t k = begin; k < end; ++k )
@@ -867,6 +980,7 @@ int Upload( PtScene* s, const PtSceneDesc* d, const std::vector< uint32_t >& esc
                 }
             } );
             HIP_TRY( s->widePrims.Upload( ordered.get(), 64ull * P ) );
+            }
             // stack entries beyond the ones the kernels keep in LDS: one slot per level and thread of the larger of the two grids
             const uint64_t lanes = std::max< uint64_t >( static_cast< uint64_t >( s->wideBlocks ) * s->wideThreads, static_cast< uint64_t >( s->wideShadowBlocks ) * s->wideShadowThreads );
             if ( wideDepth > static_cast< uint32_t >( s->wideLdsStack ) ) HIP_TRY( s->wideSpill.Allocate( 8ull * ( wideDepth - s->wideLdsStack ) * lanes ) );
@@ -1002,6 +1116,7 @@ int Upload( PtScene* s, const PtSceneDesc* d, const std::vector< uint32_t >& esc
     HIP_TRY( hipMemset( s->stats.ptr, 0, ST_COUNT * 8 ) );
     // per bounce: the two unit cursors of the traversal kernels and the length of the redo queue
     HIP_TRY( s->cursors.Allocate( 3 * 4 * static_cast< size_t >( s->maxDepth > 0 ? s->maxDepth : 1 ) ) );
+    HIP_TRY( hipDeviceSynchronize() ); // the kernels that read the description's device copy are done before it is freed
     phase( "materials, textures, film" );
     return PT_OK;
 }
@@ -1393,6 +1508,25 @@ try
 catch ( ... )
 {
     return HostFailure( "pt_readback" );
+}
+
+int pt_read_layout( PtScene* s, uint32_t which, void* dst, uint64_t capacity, uint64_t* bytes )
+try
+{
+    if ( !s ) return Fail( PT_ERR_INVALID_ARG, "pt_read_layout: null scene" );
+    const DeviceBuffer* all[] = { &s->nodes, &s->orderedNodes, &s->prims, &s->triShade, &s->wideNodes, &s->widePrims, &s->shadowNodes };
+    if ( which >= sizeof( all ) / sizeof( all[0] ) ) return Fail( PT_ERR_INVALID_ARG, "pt_read_layout: no layout %u", which );
+    const DeviceBuffer& b = *all[which];
+    if ( bytes ) *bytes = b.bytes;
+    if ( !dst || b.bytes == 0 ) return PT_OK;
+    if ( capacity < b.bytes ) return Fail( PT_ERR_INVALID_ARG, "pt_read_layout: %llu bytes needed, %llu given", (unsigned long long)b.bytes, (unsigned long long)capacity );
+    HIP_TRY( hipSetDevice( s->device ) );
+    HIP_TRY( hipMemcpy( dst, b.ptr, b.bytes, hipMemcpyDeviceToHost ) );
+    return PT_OK;
+}
+catch ( ... )
+{
+    return HostFailure( "pt_read_layout" );
 }
 
 int pt_film_device_ptr( PtScene* s, void** device_ptr, uint64_t* bytes )

@@ -1,0 +1,48 @@
+// The per-node and per-primitive records of an uploaded scene, written by kernels from the scene description as it is
+// (the reference's LinearBVHNode array, src/bvh.hpp:10-21, its shape list and the meshes' vertex arrays) instead of on
+// the host: the description crosses PCIe once, at about half the size of the records, and no host thread touches a
+// record.  Every function produces, bit for bit, what the host code in api.hip (PT_SCENE_HOST_LAYOUTS) produces.
+#pragma once
+
+#include "pt_api.h"
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ptd
+{
+
+// Device copies of the parts of a PtSceneDesc the records are made from
+struct LayoutInputs
+{
+    const PtBvhNode* nodes = nullptr;
+    uint32_t numNodes      = 0;
+    const uint32_t* escape = nullptr; // first node after the subtree of node i in the reference's pre-order
+    const PtPrim* prims    = nullptr;
+    uint64_t numPrims      = 0;
+    const PtTriangle* triangles = nullptr;
+    const PtMesh* meshes   = nullptr;
+    const float *vertices = nullptr, *normals = nullptr, *tangents = nullptr, *uvs = nullptr;
+    const PtSphere* spheres    = nullptr;
+    const uint8_t* sphereBelow = nullptr; // per node: its subtree holds a sphere; null: the scene has none
+};
+
+// First layout: 32-byte records in device order.  topSorted / topRank: the nodes of the top of the tree in ascending
+// order of their reference index, and the position of each in device order.
+void BuildReferenceNodes( hipStream_t stream, const LayoutInputs& in, const uint32_t* topSorted, const uint32_t* topRank, uint32_t topCount, float4* out );
+
+// Second layout: 64-byte records with a link per octant.  topOrder: the top of the tree in device order (the root, then
+// sibling pairs); roots / rootBase: the inner nodes of the top whose children lie below it, ascending, and the record
+// index of each one's first pair.  at, parent ( numNodes words each ), innerPrefix ( numNodes + 1 words ) and blockSums
+// ( LayoutScanBlocks( numNodes ) + 1 words ) are scratch.
+uint32_t LayoutScanBlocks( uint32_t numNodes );
+void BuildOrderedNodes( hipStream_t stream, const LayoutInputs& in, const uint32_t* topOrder, uint32_t topCount, const uint32_t* roots, const uint32_t* rootBase,
+                        uint32_t numRoots, uint32_t numOrdered, uint32_t* at, uint32_t* parent, uint32_t* innerPrefix, uint32_t* blockSums, uint4* out );
+
+// The 64-byte intersection records and the 128-byte attribute records of the primitives, reference order
+void BuildPrimRecords( hipStream_t stream, const LayoutInputs& in, float4* prims, float4* shade );
+
+// The intersection records once more in the order of the wide layout, the primitive's reference index in word 3
+void GatherWidePrims( hipStream_t stream, const LayoutInputs& in, const float4* prims, const uint32_t* primOrder, float4* widePrims );
+
+} // namespace ptd

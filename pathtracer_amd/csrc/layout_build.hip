@@ -1,0 +1,317 @@
+// Kernels that write the device records of a scene from its description (see layout_build.h).  Each mirrors a loop of
+// Upload in api.hip word for word; the host loops stay as the checker (PT_SCENE_HOST_LAYOUTS).
+#include "layout_build.h"
+#include "pt_device.h"
+
+namespace ptd
+{
+
+namespace
+{
+
+constexpr int kBlock = 256;
+constexpr uint32_t kScanItems = 16;                  // nodes per thread of the prefix count
+constexpr uint32_t kScanTile  = kBlock * kScanItems; // nodes per block
+constexpr uint32_t kUnset     = 0xFFFFFFFFu;
+
+__device__ __forceinline__ uint32_t GlobalIndex() { return blockIdx.x * kBlock + threadIdx.x; }
+
+inline uint32_t BlocksFor( uint64_t n ) { return static_cast< uint32_t >( ( n + kBlock - 1 ) / kBlock ); }
+
+// Largest k with sorted[k] <= x, or count if there is none ( sorted ascending )
+__device__ __forceinline__ uint32_t LastNotAbove( const uint32_t* __restrict__ sorted, uint32_t count, uint32_t x )
+{
+    uint32_t lo = 0, hi = count; // first element above x
+    while ( lo < hi )
+    {
+        const uint32_t mid = ( lo + hi ) >> 1;
+        if ( sorted[mid] <= x )
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return lo == 0 ? count : lo - 1;
+}
+
+// ---- first layout
+
+// Device index of reference node i: the top of the tree first, in the given order, everything else behind it in the
+// reference's order
+__device__ __forceinline__ uint32_t Place( const uint32_t* __restrict__ topSorted, const uint32_t* __restrict__ topRank, uint32_t topCount, uint32_t numNodes, uint32_t i )
+{
+    if ( i >= numNodes ) return numNodes; // the end of the traversal
+    const uint32_t k = LastNotAbove( topSorted, topCount, i );
+    if ( k != topCount && topSorted[k] == i ) return topRank[k];
+    const uint32_t before = k == topCount ? 0u : k + 1u; // top nodes with a smaller index
+    return topCount + i - before;
+}
+
+__global__ __launch_bounds__( kBlock ) void ReferenceNodesKernel( LayoutInputs in, const uint32_t* __restrict__ topSorted, const uint32_t* __restrict__ topRank,
+                                                                  uint32_t topCount, float4* __restrict__ out )
+{
+    const uint32_t i = GlobalIndex();
+    if ( i >= in.numNodes ) return;
+    const PtBvhNode n = in.nodes[i];
+    uint32_t link = Place( topSorted, topRank, topCount, in.numNodes, in.escape[i] ), word;
+    if ( n.num_shapes > 0 )
+    {
+        link |= kLeafFlag;
+        word = static_cast< uint32_t >( n.offset ) | ( static_cast< uint32_t >( n.num_shapes - 1 ) << 28 );
+    }
+    else
+        word = Place( topSorted, topRank, topCount, in.numNodes, i + 1 );
+    float4* o = out + 2ull * Place( topSorted, topRank, topCount, in.numNodes, i );
+    o[0] = make_float4( n.aabb_min[0], n.aabb_min[1], n.aabb_max[0], n.aabb_max[1] );
+    o[1] = make_float4( n.aabb_min[2], n.aabb_max[2], __uint_as_float( link ), __uint_as_float( word ) );
+}
+
+// ---- second layout
+
+// innerPrefix[i] = inner nodes with a reference index below i, i = 0 .. numNodes: block totals, their scan, the rest
+__device__ __forceinline__ uint32_t InnerFlag( const LayoutInputs& in, uint32_t i ) { return i < in.numNodes && in.nodes[i].num_shapes == 0 ? 1u : 0u; }
+
+__global__ __launch_bounds__( kBlock ) void InnerCountKernel( LayoutInputs in, uint32_t* __restrict__ blockSums )
+{
+    __shared__ uint32_t total;
+    if ( threadIdx.x == 0 ) total = 0;
+    __syncthreads();
+    const uint32_t first = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+    uint32_t mine = 0;
+    for ( uint32_t k = 0; k < kScanItems; ++k ) mine += InnerFlag( in, first + k );
+    atomicAdd( &total, mine );
+    __syncthreads();
+    if ( threadIdx.x == 0 ) blockSums[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__( 1 ) void ScanBlockSumsKernel( uint32_t* __restrict__ blockSums, uint32_t count )
+{
+    // a few thousand entries at most: one thread
+    uint32_t run = 0;
+    for ( uint32_t k = 0; k < count; ++k )
+    {
+        const uint32_t v = blockSums[k];
+        blockSums[k] = run;
+        run += v;
+    }
+    blockSums[count] = run;
+}
+
+__global__ __launch_bounds__( kBlock ) void InnerPrefixKernel( LayoutInputs in, const uint32_t* __restrict__ blockSums, uint32_t* __restrict__ innerPrefix )
+{
+    __shared__ uint32_t sums[kBlock];
+    const uint32_t first = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+    uint32_t flags = 0, mine = 0;
+    for ( uint32_t k = 0; k < kScanItems; ++k )
+    {
+        const uint32_t f = InnerFlag( in, first + k );
+        flags |= f << k;
+        mine += f;
+    }
+    sums[threadIdx.x] = mine;
+    __syncthreads();
+    for ( uint32_t step = 1; step < kBlock; step <<= 1 )
+    {
+        const uint32_t add = threadIdx.x >= step ? sums[threadIdx.x - step] : 0u;
+        __syncthreads();
+        sums[threadIdx.x] += add;
+        __syncthreads();
+    }
+    uint32_t run = blockSums[blockIdx.x] + sums[threadIdx.x] - mine;
+    for ( uint32_t k = 0; k < kScanItems; ++k )
+    {
+        if ( first + k <= in.numNodes ) innerPrefix[first + k] = run;
+        run += ( flags >> k ) & 1u;
+    }
+}
+
+__global__ __launch_bounds__( kBlock ) void TopRecordsKernel( const uint32_t* __restrict__ topOrder, uint32_t topCount, uint32_t* __restrict__ at )
+{
+    // the root at 0, record 1 unused, then the sibling pairs of the top in their order
+    const uint32_t k = GlobalIndex();
+    if ( k < topCount ) at[topOrder[k]] = k == 0 ? 0u : k + 1u;
+}
+
+// Below the top a pair of children is followed by the first child's subtree, then the second's: the pairs of a subtree
+// come in the pre-order of their parents, so the position of a pair is the number of inner nodes before its parent
+__global__ __launch_bounds__( kBlock ) void PairRecordsKernel( LayoutInputs in, const uint32_t* __restrict__ roots, const uint32_t* __restrict__ rootBase, uint32_t numRoots,
+                                                               const uint32_t* __restrict__ innerPrefix, uint32_t* __restrict__ at, uint32_t* __restrict__ parent )
+{
+    const uint32_t x = GlobalIndex();
+    if ( x >= in.numNodes ) return;
+    if ( x == 0 ) parent[0] = kUnset;
+    const PtBvhNode n = in.nodes[x];
+    if ( n.num_shapes > 0 ) return;
+    const uint32_t a = x + 1, b = static_cast< uint32_t >( n.offset );
+    parent[a] = x;
+    parent[b] = x;
+    if ( at[a] != kUnset ) return; // a pair of the top (only this thread ever writes at[a])
+    const uint32_t j    = LastNotAbove( roots, numRoots, x );
+    const uint32_t pair = rootBase[j] + 2u * ( innerPrefix[x] - innerPrefix[roots[j]] );
+    at[a] = pair;
+    at[b] = pair + 1u;
+}
+
+__global__ __launch_bounds__( kBlock ) void OrderedNodesKernel( LayoutInputs in, const uint32_t* __restrict__ at, const uint32_t* __restrict__ parent, uint32_t numOrdered,
+                                                                uint4* __restrict__ out )
+{
+    const uint32_t i = GlobalIndex();
+    if ( i == 0 ) out[4] = out[5] = out[6] = out[7] = make_uint4( 0u, 0u, 0u, 0u ); // record 1
+    if ( i >= in.numNodes ) return;
+    const PtBvhNode n = in.nodes[i];
+    const uint32_t below = in.sphereBelow && in.sphereBelow[i] ? kSphereBelowFlag : 0u;
+    uint32_t w6, w7;
+    if ( n.num_shapes > 0 )
+    {
+        w6 = static_cast< uint32_t >( n.offset ) | ( static_cast< uint32_t >( n.num_shapes - 1 ) << 28 );
+        w7 = kLeafFlag | below;
+    }
+    else
+    {
+        w6 = at[i + 1];
+        w7 = ( 2u + ( n.axis < 3 ? n.axis : 0u ) ) | below;
+    }
+    // Per octant of ray directions the record that follows this node's subtree when near children go first: the sibling
+    // of the first node on the way up that is its parent's near child, or the end.  Half of the octants are settled at
+    // every level whose split axis is new, so the walk is short.
+    uint32_t links[8];
+    for ( int o = 0; o < 8; ++o ) links[o] = numOrdered;
+    uint32_t open = 0xFFu;
+    for ( uint32_t y = i; open != 0 && y != 0; )
+    {
+        const uint32_t p   = parent[y];
+        const PtBvhNode pn = in.nodes[p];
+        const uint32_t axis = pn.axis < 3 ? pn.axis : 0u;
+        const bool first    = y == p + 1;
+        const uint32_t lowSide = axis == 0 ? 0x55u : axis == 1 ? 0x33u : 0x0Fu; // octants whose bit `axis` is clear: the first child is the near one
+        const uint32_t mine    = open & ( first ? lowSide : ~lowSide );
+        if ( mine )
+        {
+            const uint32_t sibling = at[first ? static_cast< uint32_t >( pn.offset ) : p + 1];
+            for ( int o = 0; o < 8; ++o )
+                if ( ( mine >> o ) & 1u ) links[o] = sibling;
+            open &= ~mine;
+        }
+        y = p;
+    }
+    uint4* r = out + 4ull * at[i];
+    r[0] = make_uint4( __float_as_uint( n.aabb_min[0] ), __float_as_uint( n.aabb_min[1] ), __float_as_uint( n.aabb_max[0] ), __float_as_uint( n.aabb_max[1] ) );
+    r[1] = make_uint4( __float_as_uint( n.aabb_min[2] ), __float_as_uint( n.aabb_max[2] ), w6, w7 );
+    r[2] = make_uint4( links[0], links[1], links[2], links[3] );
+    r[3] = make_uint4( links[4], links[5], links[6], links[7] );
+}
+
+// ---- primitives
+
+__device__ __forceinline__ const float* VertexOf( const float* attribute, const PtMesh& m, uint32_t index, int stride )
+{
+    return attribute + static_cast< size_t >( stride ) * ( m.vertex_offset + index );
+}
+
+__global__ __launch_bounds__( kBlock ) void PrimRecordsKernel( LayoutInputs in, float4* __restrict__ prims, float4* __restrict__ shade )
+{
+    const uint64_t i = static_cast< uint64_t >( blockIdx.x ) * kBlock + threadIdx.x;
+    if ( i >= in.numPrims ) return;
+    const PtPrim p = in.prims[i];
+    float q[16], a[32];
+    for ( int k = 0; k < 16; ++k ) q[k] = 0.0f;
+    for ( int k = 0; k < 32; ++k ) a[k] = 0.0f;
+    if ( p.type == PT_PRIM_TRIANGLE )
+    {
+        const PtTriangle t = in.triangles[p.index];
+        const PtMesh m     = in.meshes[t.mesh];
+        const uint32_t idx[3] = { t.i0, t.i1, t.i2 };
+        const float *v0 = VertexOf( in.vertices, m, t.i0, 3 ), *v1 = VertexOf( in.vertices, m, t.i1, 3 ), *v2 = VertexOf( in.vertices, m, t.i2, 3 );
+        q[0] = v0[0]; q[1] = v0[1]; q[2] = v0[2];
+        q[3] = __uint_as_float( kTagTriangle );
+        q[4] = v1[0] - v0[0]; q[5] = v1[1] - v0[1]; q[6]  = v1[2] - v0[2]; // v0v1 of src/intersection_tests.cpp:37
+        q[8] = v2[0] - v0[0]; q[9] = v2[1] - v0[1]; q[10] = v2[2] - v0[2]; // v0v2 of src/intersection_tests.cpp:38
+        for ( int k = 0; k < 3; ++k )
+        {
+            const float *nn = VertexOf( in.normals, m, idx[k], 3 ), *tt = VertexOf( in.tangents, m, idx[k], 3 ), *uv = VertexOf( in.uvs, m, idx[k], 2 );
+            a[3 * k] = nn[0]; a[3 * k + 1] = nn[1]; a[3 * k + 2] = nn[2];
+            a[9 + 3 * k] = tt[0]; a[10 + 3 * k] = tt[1]; a[11 + 3 * k] = tt[2];
+            a[18 + 2 * k] = uv[0]; a[19 + 2 * k] = uv[1];
+        }
+        a[24] = __int_as_float( m.material );
+    }
+    else
+    {
+        const PtSphere sp = in.spheres[p.index];
+        q[0] = sp.position[0]; q[1] = sp.position[1]; q[2] = sp.position[2];
+        q[3] = __uint_as_float( kTagSphere );
+        q[4] = sp.radius;
+        q[5] = __uint_as_float( p.index );
+    }
+    // words 7, 11 and 12 - 15 become the leaf's box (LeafBoxKernel, which runs after this one)
+    float4* qo = prims + 4 * i;
+    for ( int k = 0; k < 4; ++k ) qo[k] = make_float4( q[4 * k], q[4 * k + 1], q[4 * k + 2], q[4 * k + 3] );
+    float4* ao = shade + 8 * i;
+    for ( int k = 0; k < 8; ++k ) ao[k] = make_float4( a[4 * k], a[4 * k + 1], a[4 * k + 2], a[4 * k + 3] );
+}
+
+__global__ __launch_bounds__( kBlock ) void LeafBoxKernel( LayoutInputs in, float4* __restrict__ prims )
+{
+    const uint32_t i = GlobalIndex();
+    if ( i >= in.numNodes ) return;
+    const PtBvhNode n = in.nodes[i];
+    for ( uint32_t k = 0; k < n.num_shapes; ++k )
+    {
+        float* q = reinterpret_cast< float* >( prims + 4ull * ( static_cast< uint64_t >( n.offset ) + k ) );
+        q[7]  = n.aabb_min[0]; q[11] = n.aabb_min[1]; q[12] = n.aabb_min[2];
+        q[13] = n.aabb_max[0]; q[14] = n.aabb_max[1]; q[15] = n.aabb_max[2];
+    }
+}
+
+__global__ __launch_bounds__( kBlock ) void WidePrimsKernel( LayoutInputs in, const float4* __restrict__ prims, const uint32_t* __restrict__ primOrder, float4* __restrict__ widePrims )
+{
+    const uint64_t k = static_cast< uint64_t >( blockIdx.x ) * kBlock + threadIdx.x;
+    if ( k >= in.numPrims ) return;
+    const uint32_t i = primOrder[k];
+    const float4* q  = prims + 4ull * i;
+    float4 q0 = q[0];
+    q0.w = __uint_as_float( i | ( in.prims[i].type == PT_PRIM_SPHERE ? 0x80000000u : 0u ) );
+    float4* o = widePrims + 4 * k;
+    o[0] = q0;
+    o[1] = q[1];
+    o[2] = q[2];
+    o[3] = q[3];
+}
+
+} // namespace
+
+void BuildReferenceNodes( hipStream_t stream, const LayoutInputs& in, const uint32_t* topSorted, const uint32_t* topRank, uint32_t topCount, float4* out )
+{
+    if ( in.numNodes == 0 ) return;
+    hipLaunchKernelGGL( ReferenceNodesKernel, dim3( BlocksFor( in.numNodes ) ), dim3( kBlock ), 0, stream, in, topSorted, topRank, topCount, out );
+}
+
+uint32_t LayoutScanBlocks( uint32_t numNodes ) { return numNodes / kScanTile + 1u; } // covers index numNodes too
+
+void BuildOrderedNodes( hipStream_t stream, const LayoutInputs& in, const uint32_t* topOrder, uint32_t topCount, const uint32_t* roots, const uint32_t* rootBase,
+                        uint32_t numRoots, uint32_t numOrdered, uint32_t* at, uint32_t* parent, uint32_t* innerPrefix, uint32_t* blockSums, uint4* out )
+{
+    if ( in.numNodes == 0 ) return;
+    const uint32_t scanBlocks = LayoutScanBlocks( in.numNodes );
+    hipLaunchKernelGGL( InnerCountKernel, dim3( scanBlocks ), dim3( kBlock ), 0, stream, in, blockSums );
+    hipLaunchKernelGGL( ScanBlockSumsKernel, dim3( 1 ), dim3( 1 ), 0, stream, blockSums, scanBlocks );
+    hipLaunchKernelGGL( InnerPrefixKernel, dim3( scanBlocks ), dim3( kBlock ), 0, stream, in, blockSums, innerPrefix );
+    (void)hipMemsetAsync( at, 0xFF, 4ull * in.numNodes, stream );
+    hipLaunchKernelGGL( TopRecordsKernel, dim3( BlocksFor( topCount ) ), dim3( kBlock ), 0, stream, topOrder, topCount, at );
+    hipLaunchKernelGGL( PairRecordsKernel, dim3( BlocksFor( in.numNodes ) ), dim3( kBlock ), 0, stream, in, roots, rootBase, numRoots, innerPrefix, at, parent );
+    hipLaunchKernelGGL( OrderedNodesKernel, dim3( BlocksFor( in.numNodes ) ), dim3( kBlock ), 0, stream, in, at, parent, numOrdered, out );
+}
+
+void BuildPrimRecords( hipStream_t stream, const LayoutInputs& in, float4* prims, float4* shade )
+{
+    if ( in.numPrims == 0 ) return;
+    hipLaunchKernelGGL( PrimRecordsKernel, dim3( BlocksFor( in.numPrims ) ), dim3( kBlock ), 0, stream, in, prims, shade );
+    hipLaunchKernelGGL( LeafBoxKernel, dim3( BlocksFor( in.numNodes ) ), dim3( kBlock ), 0, stream, in, prims );
+}
+
+void GatherWidePrims( hipStream_t stream, const LayoutInputs& in, const float4* prims, const uint32_t* primOrder, float4* widePrims )
+{
+    if ( in.numPrims == 0 ) return;
+    hipLaunchKernelGGL( WidePrimsKernel, dim3( BlocksFor( in.numPrims ) ), dim3( kBlock ), 0, stream, in, prims, primOrder, widePrims );
+}
+
+} // namespace ptd

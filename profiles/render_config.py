@@ -18,6 +18,7 @@ p.add_argument("--width", type=int, default=0)
 p.add_argument("--height", type=int, default=0)
 p.add_argument("--depth", type=int, default=-1)
 p.add_argument("--traversal", choices=("wide", "ordered", "reference"), default="ordered")
+p.add_argument("--host-layouts", action="store_true", help="PT_SCENE_HOST_LAYOUTS: records written on the host")
 a = p.parse_args()
 
 if a.scene == "cornell":
@@ -41,7 +42,10 @@ with hs:
         hs.set_image(a.width, a.height, a.width / a.height)
     if a.depth >= 0:
         hs.set_max_depth(a.depth)
-    with api.DeviceScene(hs.desc()) as dev:
+    desc = hs.desc()
+    if a.host_layouts:
+        desc.flags |= 32  # PT_SCENE_HOST_LAYOUTS
+    with api.DeviceScene(desc) as dev:
         dev.render(a.spp, seed=0, ordered=a.traversal != "reference", wide=a.traversal == "wide", wide_shadows=a.traversal == "wide")
         _, _, st = dev.readback()
         rays = st.rays_closest + st.rays_shadow

@@ -8,10 +8,10 @@
 # PT_WIDE_LEAF_LANES / PT_WIDE_BURST (closest hit over the wide layout) (kernels.hip); PT_TOP_NODES is an environment
 # variable read at upload.
 mkdir -p variants/obj
-for f in api bvh_build wide_bvh; do
+for f in api bvh_build wide_bvh layout_build; do
   if [ ! -f variants/obj/$f.o ] || [ pathtracer_amd/csrc/$f.hip -nt variants/obj/$f.o ]; then
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -std=c++17 -O3 -fPIC -ffp-contract=off -fno-fast-math -Iinclude -c pathtracer_amd/csrc/$f.hip -o variants/obj/$f.o
   fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -std=c++17 -O3 -fPIC -ffp-contract=off -fno-fast-math -Iinclude $2 -shared \
-    -o variants/$1.so variants/obj/api.o variants/obj/bvh_build.o variants/obj/wide_bvh.o pathtracer_amd/csrc/kernels.hip
+    -o variants/$1.so variants/obj/api.o variants/obj/bvh_build.o variants/obj/wide_bvh.o variants/obj/layout_build.o pathtracer_amd/csrc/kernels.hip
