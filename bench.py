@@ -288,9 +288,11 @@ def main():
             # The roofline this tier asks for is the memory one: bytes that left the L2 per launch over the launch's time,
             # against the HBM peak.  The scene's records sit in the caches, so that fraction is small and says that memory
             # does not bound the kernel; `ceilings` says what does - each unit as busy cycles over the cycles it had: the
-            # SIMDs' vector issue (1,024 SIMDs; SQ_ACTIVE_INST_VALU counts four cycles an instruction, which is what most
-            # vector instructions occupy a SIMD for: profiles/microbench/valu_rate.hip), the texture addressers through
-            # which every vector memory instruction passes (one per CU; TA_TA_BUSY), the scalar units (one per CU).
+            # SIMDs' vector issue (1,024 SIMDs; SQ_ACTIVE_INST_VALU at four cycles an instruction, which is what one wave's
+            # vector instruction occupies a SIMD for - with several waves resident a SIMD gets plain fp32 instructions
+            # through in about 2.7, profiles/microbench/valu_rate.hip, so that the figure can pass 1: read that as
+            # saturated), the texture addressers through which every vector memory instruction passes (one per CU;
+            # TA_TA_BUSY), the scalar units (one per CU).
             ta_busy = per.get("TA_TA_BUSY_sum", 0.0)
             ceilings = {"valu_issue": (busy, 1024 * cycles), "texture_addresser": (ta_busy, 256 * cycles)}
             if per.get("SQ_INSTS_SALU"):   # one scalar unit per CU, at most one instruction per cycle

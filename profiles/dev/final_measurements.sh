@@ -1,0 +1,16 @@
+#!/bin/bash
+# On the GPU box, from the repository root: everything the round's tables are made from, into gpurun_out/<tag>_*.
+# usage: profiles/dev/final_measurements.sh <tag>
+set -u
+TAG=${1:-r03}
+OUT=gpurun_out
+for m in wide ordered reference; do
+  timeout -k 10 420 profiles/collect_pmc.sh ${TAG}_$m $m > /dev/null 2>&1 || { echo "collect $m failed"; exit 1; }
+done
+timeout -k 10 400 python3 bench.py > $OUT/${TAG}_bench_wide.json 2> $OUT/${TAG}_bench_wide.err || { echo "bench failed"; exit 1; }
+for m in ordered reference; do
+  timeout -k 10 300 python3 bench.py --traversal $m --cpu-baseline-spp 0 > $OUT/${TAG}_bench_$m.json 2> $OUT/${TAG}_bench_$m.err || { echo "bench $m failed"; exit 1; }
+done
+timeout -k 10 900 python3 profiles/other_configs.py --traversal all > $OUT/${TAG}_other_configs.jsonl 2> $OUT/${TAG}_other_configs.err || { echo "other configs failed"; exit 1; }
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 profiles/microbench/valu_rate.hip -o /tmp/valu_rate && timeout -k 10 60 /tmp/valu_rate > $OUT/${TAG}_valu_rate.txt 2>&1
+tail -c 600 $OUT/${TAG}_bench_wide.json
