@@ -1112,8 +1112,8 @@ int Upload( PtScene* s, const PtSceneDesc* d, const std::vector< uint32_t >& esc
     const size_t pixels = static_cast< size_t >( s->width ) * s->height;
     HIP_TRY( s->film.Allocate( pixels * 16 ) );
     HIP_TRY( hipMemset( s->film.ptr, 0, pixels * 16 ) );
-    HIP_TRY( s->stats.Allocate( ST_COUNT * 8 ) );
-    HIP_TRY( hipMemset( s->stats.ptr, 0, ST_COUNT * 8 ) );
+    HIP_TRY( s->stats.Allocate( kStatsWords * 8 ) );
+    HIP_TRY( hipMemset( s->stats.ptr, 0, kStatsWords * 8 ) );
     // per bounce: the two unit cursors of the traversal kernels and the length of the redo queue
     HIP_TRY( s->cursors.Allocate( 3 * 4 * static_cast< size_t >( s->maxDepth > 0 ? s->maxDepth : 1 ) ) );
     HIP_TRY( hipDeviceSynchronize() ); // the kernels that read the description's device copy are done before it is freed
@@ -1483,8 +1483,9 @@ try
     }
     if ( stats )
     {
-        uint64_t dev[ST_COUNT];
-        HIP_TRY( hipMemcpy( dev, s->stats.ptr, sizeof( dev ), hipMemcpyDeviceToHost ) );
+        std::vector< uint64_t > dev( kStatsWords );
+        HIP_TRY( hipMemcpy( dev.data(), s->stats.ptr, kStatsWords * 8, hipMemcpyDeviceToHost ) );
+        for ( uint32_t k = 0; k < kShadedSlots; ++k ) dev[ST_SHADED] += dev[ST_COUNT + static_cast< size_t >( k ) * kShadedStride]; // see kShadedSlots
         std::memset( stats, 0, sizeof( *stats ) );
         stats->samples              = s->samples;
         stats->rays_closest         = dev[ST_RAYS_CLOSEST];

@@ -1007,15 +1007,28 @@ struct UnitStream
     const uint32_t* counts; // entries per unit, or null: all paths of the pass (bounce 0)
     uint32_t numUnits, entriesPerUnit, numPaths;
     uint32_t base = 0, count = 0, taken = 0; // current unit: first entry, entries, entries handed out
+    uint32_t nextUnit = 0, unitsHeld = 0;    // units taken from the cursor and not started yet
     bool ended = false;
 };
+
+// Units a wave takes from the cursor at a time: an atomic with a result is a round trip to the L2 during which the
+// whole wave stands still, and all waves of a launch use the one address
+#ifndef PT_UNIT_BATCH
+#define PT_UNIT_BATCH 2
+#endif
 
 // Moves on to the next unit; false once the cursor has passed the last one.  Whole wave.
 __device__ __forceinline__ bool NextUnit( UnitStream& s )
 {
-    uint32_t unit = 0;
-    if ( LaneIndex() == 0 ) unit = atomicAdd( s.cursor, 1u );
-    unit = __builtin_amdgcn_readfirstlane( unit );
+    if ( s.unitsHeld == 0 )
+    {
+        uint32_t first = 0;
+        if ( LaneIndex() == 0 ) first = atomicAdd( s.cursor, static_cast< uint32_t >( PT_UNIT_BATCH ) );
+        s.nextUnit  = __builtin_amdgcn_readfirstlane( first );
+        s.unitsHeld = PT_UNIT_BATCH;
+    }
+    const uint32_t unit = s.nextUnit++;
+    s.unitsHeld--;
     if ( unit >= s.numUnits )
     {
         s.ended = true;
@@ -1321,10 +1334,20 @@ __global__ __launch_bounds__( kBlock ) void RedoKernel( SceneView sv, PathBuffer
 #define PT_WIDE_REFILL_LANES 24
 #endif
 #ifndef PT_WIDE_LEAF_LANES
-#define PT_WIDE_LEAF_LANES 12
+#define PT_WIDE_LEAF_LANES 16
 #endif
 #ifndef PT_WIDE_BURST
 #define PT_WIDE_BURST 2
+#endif
+// the same three for the any-hit kernel over the wide layout
+#ifndef PT_WIDE_SHADOW_REFILL_LANES
+#define PT_WIDE_SHADOW_REFILL_LANES 24
+#endif
+#ifndef PT_WIDE_SHADOW_LEAF_LANES
+#define PT_WIDE_SHADOW_LEAF_LANES 28
+#endif
+#ifndef PT_WIDE_SHADOW_BURST
+#define PT_WIDE_SHADOW_BURST 2
 #endif
 constexpr int kWideBlock = PT_WIDE_BLOCK, kWideSphereBlock = PT_WIDE_SPHERE_BLOCK;
 constexpr uint32_t kWideLdsStack = PT_WIDE_LDS_STACK;
@@ -1650,7 +1673,7 @@ void ConnectWideKernel( SceneView sv, PathBuffers pb, int bounce, uint2* spill, 
         const unsigned long long mRay  = mIdle & ( stream.ended ? Ballot( rec != kNoRay ) : ~0ull );
         if ( ( mLeaf | mTrav | mRay ) == 0 ) break;
 
-        if ( mRay && ( __popcll( mRay ) >= PT_WIDE_REFILL_LANES || ( mTrav | mLeaf ) == 0 ) )
+        if ( mRay && ( __popcll( mRay ) >= PT_WIDE_SHADOW_REFILL_LANES || ( mTrav | mLeaf ) == 0 ) )
         {
             if constexpr ( kDirectSum )
             {
@@ -1702,7 +1725,7 @@ void ConnectWideKernel( SceneView sv, PathBuffers pb, int bounce, uint2* spill, 
             continue;
         }
 
-        if ( mLeaf && ( __popcll( mLeaf ) >= PT_WIDE_LEAF_LANES || mTrav == 0 ) )
+        if ( mLeaf && ( __popcll( mLeaf ) >= PT_WIDE_SHADOW_LEAF_LANES || mTrav == 0 ) )
         {
             for ( ;; )
             {
@@ -1728,7 +1751,7 @@ void ConnectWideKernel( SceneView sv, PathBuffers pb, int bounce, uint2* spill, 
         }
 
         const uint32_t started = static_cast< uint32_t >( __popcll( mTrav ) );
-        for ( int burst = 0; burst < PT_WIDE_BURST; ++burst )
+        for ( int burst = 0; burst < PT_WIDE_SHADOW_BURST; ++burst )
         {
             const bool go = ( leafBits & 0xFFu ) == 0 && sp != 0;
             const uint32_t active = LanesSet( go );
@@ -2183,9 +2206,9 @@ __global__ __launch_bounds__( kBlock ) void ShadeKernel( SceneView sv, RngParams
             {
                 const uint32_t next = segment + nNext + LanesBelow( mAlive );
                 pb.queue[nxt][next] = p;
-                pb.rayO[nxt][next]  = F4( sf.position, 0.0f );
-                pb.rayD[nxt][next]  = F4( nextD, 0.0f );
-                pb.thr[nxt][next]   = F4( nextT, 0.0f );
+                pb.rayO[nxt][next] = F4( sf.position, 0.0f );
+                pb.rayD[nxt][next] = F4( nextD, 0.0f );
+                pb.thr[nxt][next] = F4( nextT, 0.0f );
             }
             nNext += static_cast< uint32_t >( __popcll( mAlive ) );
         }
@@ -2199,7 +2222,7 @@ __global__ __launch_bounds__( kBlock ) void ShadeKernel( SceneView sv, RngParams
         *UnitCount( pb, bounce, kCountShadowRays, unit )  = nShadowRays;
         if constexpr ( !kSphereHits ) *UnitCount( pb, bounce, kCountSphereHits, unit ) = nSpheres;
     }
-    FlushWaveCounter( stats, ST_SHADED, waveShaded );
+    FlushWaveCounter( stats, ST_COUNT + static_cast< int >( ( unit % kShadedSlots ) * kShadedStride ), waveShaded ); // see kShadedSlots
 }
 
 // L += throughput * sum over lights of ( sum over the unoccluded samples ) / nSamples (path_tracer.cpp:90-104,

@@ -159,6 +159,11 @@ enum
     ST_RAYS_CLOSEST, ST_RAYS_SHADOW, ST_NODES_CLOSEST, ST_NODES_SHADOW, ST_TRI_CLOSEST, ST_TRI_SHADOW,
     ST_SPH_CLOSEST, ST_SPH_SHADOW, ST_SHADED, ST_STEPS_CLOSEST, ST_STEPS_SHADOW, ST_RAYS_REDONE, ST_COUNT
 };
+// The shading kernel runs one wave per unit of 256 paths - a million waves per launch of a large pass - and atomics on
+// one address complete one after the other (about 13 ns each: 13 ms per launch, measured).  Its count of shaded hits
+// therefore goes to one of kShadedSlots counters behind the block, 128 bytes apart; the read-back sums them.
+constexpr uint32_t kShadedSlots = 4096, kShadedStride = 16; // counters, and the distance between two in 64-bit words
+constexpr size_t kStatsWords = ST_COUNT + static_cast< size_t >( kShadedSlots ) * kShadedStride;
 
 struct LaunchCfg
 {

@@ -12,5 +12,12 @@ for m in ordered reference; do
   timeout -k 10 300 python3 bench.py --traversal $m --cpu-baseline-spp 0 > $OUT/${TAG}_bench_$m.json 2> $OUT/${TAG}_bench_$m.err || { echo "bench $m failed"; exit 1; }
 done
 timeout -k 10 900 python3 profiles/other_configs.py --traversal all > $OUT/${TAG}_other_configs.jsonl 2> $OUT/${TAG}_other_configs.err || { echo "other configs failed"; exit 1; }
+for m in wide ordered reference; do
+  timeout -k 10 300 profiles/collect_pmc.sh ${TAG}_knot_$m profiles/render_config.py knot --spp 16 --traversal $m > /dev/null 2>&1 || { echo "knot $m failed"; exit 1; }
+  timeout -k 10 300 profiles/collect_pmc.sh ${TAG}_cornell_$m profiles/render_config.py cornell --spp 64 --traversal $m > /dev/null 2>&1 || { echo "cornell $m failed"; exit 1; }
+done
+for m in wide ordered; do
+  timeout -k 10 500 profiles/collect_pmc.sh ${TAG}_soup_$m profiles/render_config.py soup --spp 4 --traversal $m > /dev/null 2>&1 || { echo "soup $m failed"; exit 1; }
+done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 profiles/microbench/valu_rate.hip -o /tmp/valu_rate && timeout -k 10 60 /tmp/valu_rate > $OUT/${TAG}_valu_rate.txt 2>&1
 tail -c 600 $OUT/${TAG}_bench_wide.json
