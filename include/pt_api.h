@@ -239,14 +239,21 @@ enum
  *   reference's answer depends on its order only among hits that lie within rounding of one another (coplanar or
  *   coincident surfaces, shared edges: whether a box is culled by a hit found earlier can hinge on one ulp).  The
  *   ordered pass keeps everything within a factor 1 + 2^-12 of the closest distance alive, and a ray that saw a
- *   second hit inside that band is traced again in the reference's order (PtStats::rays_redone).  Same primitive, t,
- *   u, v as PT_TRAVERSAL_REFERENCE; the node and test counters differ.
+ *   second hit inside that band is traced again in the reference's order (PtStats::rays_redone), as is a ray whose hit
+ *   lies in front of its own primitive's box.  Same primitive, t, u, v as PT_TRAVERSAL_REFERENCE; the node and test
+ *   counters differ.  One class of rays is outside that statement: a ray for which the REFERENCE's answer is a
+ *   primitive whose computed t lies in front of the primitive's bounding box by more than the band - an ill-conditioned
+ *   primitive test (a ray that grazes a triangle's plane from far away, a sliver triangle), whose hit point is not on
+ *   the primitive - while a sound hit lies between: a traversal that culls boxes by distance does not test that
+ *   primitive and returns the sound hit.  None among the 2.7 G closest-hit rays of three 128-sample frames of the
+ *   Sponza-class scene; 0.005 % of rays built to provoke it (profiles/soak_traversal.py).  Hosts that need the
+ *   reference's answer for those too use PT_TRAVERSAL_REFERENCE.
  * PT_TRAVERSAL_WIDE: over the tree collapsed into nodes of up to eight children whose boxes are stored as 8-bit offsets
  *   on a grid over the node's box, rounded outwards; children are visited front to back by the octant of the ray's
  *   direction, with a short stack per ray.  The quantised boxes only select candidates: a primitive counts if the
  *   reference's own test of its leaf's box (src/bvh.cpp:242) passes, and the rules of PT_TRAVERSAL_ORDERED about hits
- *   within rounding of one another apply.  Same primitive, t, u, v and occlusion answers as PT_TRAVERSAL_REFERENCE;
- *   nodes_visited counts wide nodes. */
+ *   within rounding of one another apply, and so does its one exception.  Same primitive, t, u, v and occlusion
+ *   answers as PT_TRAVERSAL_REFERENCE; nodes_visited counts wide nodes. */
 enum
 {
     PT_TRAVERSAL_REFERENCE = 0,

@@ -398,7 +398,10 @@ static int bvh_occluded( const PtSceneDesc* d, v3 o, v3 dir, float tMax, TravCou
  * within rounding of one another, so the closest-hit pass keeps everything within PTO_BAND of the closest distance
  * alive (boxes entered with tMin <= PTO_BAND * t) and, when a second hit lay inside that band, runs the reference's
  * own order afterwards and returns its answer; the counters are the sums of both passes.  A plain stack of far
- * children here; the GPU side follows per-octant links instead, so equal per-ray counters check both. */
+ * children here; the GPU side follows per-octant links instead, so equal per-ray counters check both.
+ * The one exception, as on the GPU (include/pt_api.h, PT_TRAVERSAL_ORDERED): when the reference's answer is a primitive
+ * whose computed t lies in front of the primitive's own box by more than the band (an ill-conditioned test) and a sound
+ * hit lies between, this order returns the sound hit - it never tests the other primitive. */
 static int bvh_intersect_ordered( const PtSceneDesc* d, const uint8_t* sphere_below, v3 o, v3 dir, Hit* hit, TravCount* cnt )
 {
     int stack[128];
