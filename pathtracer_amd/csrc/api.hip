@@ -951,7 +951,26 @@ int Upload( PtScene* s, const PtSceneDesc* d, const std::vector< uint32_t >& esc
     if ( !( d->flags & PT_SCENE_NO_WIDE_LAYOUT ) )
     {
         WideLayout wide;
-        if ( BuildWideLayout( d, escape, sphereBelow.empty() ? nullptr : sphereBelow.data(), wide ) )
+        WideDeviceLayout onDevice;
+        // below the top of the tree the collapse runs in kernels too; if that cannot be (device memory), on host threads
+        if ( !hostLayouts && BuildWideLayoutOnDevice( d, escape, sphereBelow.empty() ? nullptr : sphereBelow.data(), in.nodes, in.prims, in.sphereBelow, onDevice ) )
+        {
+            numWide   = onDevice.numNodes;
+            wideDepth = onDevice.depth;
+            s->wideNodes.Release();
+            s->wideNodes.ptr   = onDevice.nodes;
+            s->wideNodes.bytes = onDevice.nodeBytes;
+            DeviceBuffer dOrder;
+            dOrder.ptr   = onDevice.primOrder;
+            dOrder.bytes = 4ull * P;
+            HIP_TRY( s->widePrims.Allocate( 64ull * P ) );
+            GatherWidePrims( nullptr, in, s->prims.As< float4 >(), dOrder.As< uint32_t >(), s->widePrims.As< float4 >() );
+            HIP_TRY( hipGetLastError() );
+            HIP_TRY( hipDeviceSynchronize() );
+            const uint64_t lanes = std::max< uint64_t >( static_cast< uint64_t >( s->wideBlocks ) * s->wideThreads, static_cast< uint64_t >( s->wideShadowBlocks ) * s->wideShadowThreads );
+            if ( wideDepth > static_cast< uint32_t >( s->wideLdsStack ) ) HIP_TRY( s->wideSpill.Allocate( 8ull * ( wideDepth - s->wideLdsStack ) * lanes ) );
+        }
+        else if ( BuildWideLayout( d, escape, sphereBelow.empty() ? nullptr : sphereBelow.data(), wide ) )
         {
             numWide   = static_cast< uint32_t >( wide.nodes.size() / kWideNodeWords );
             wideDepth = wide.depth;

@@ -47,4 +47,17 @@ struct WideLayout
 // sphereBelow: per node of the reference's tree, whether its subtree holds a sphere; null: the scene has none.
 bool BuildWideLayout( const PtSceneDesc* d, const std::vector< uint32_t >& escape, const uint8_t* sphereBelow, WideLayout& out );
 
+// The same layout with everything below the top of the tree built by kernels, from device copies of the node array, the
+// shape list and sphereBelow: the same records and the same primitive order, left in device memory (hipMalloc; the
+// caller frees both).  False as above, or if the device runs out of memory: the caller then builds on the host.
+struct WideDeviceLayout
+{
+    void* nodes         = nullptr; // numNodes * kWideNodeWords words
+    uint32_t* primOrder = nullptr; // num_prims words
+    uint64_t nodeBytes  = 0;
+    uint32_t numNodes = 0, depth = 0;
+};
+bool BuildWideLayoutOnDevice( const PtSceneDesc* d, const std::vector< uint32_t >& escape, const uint8_t* sphereBelow, const PtBvhNode* deviceNodes,
+                              const PtPrim* devicePrims, const uint8_t* deviceSphereBelow, WideDeviceLayout& out );
+
 } // namespace ptd
