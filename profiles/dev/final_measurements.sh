@@ -20,4 +20,7 @@ for m in wide ordered; do
   timeout -k 10 500 profiles/collect_pmc.sh ${TAG}_soup_$m profiles/render_config.py soup --spp 4 --traversal $m > /dev/null 2>&1 || { echo "soup $m failed"; exit 1; }
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 profiles/microbench/valu_rate.hip -o /tmp/valu_rate && timeout -k 10 60 /tmp/valu_rate > $OUT/${TAG}_valu_rate.txt 2>&1
+# the configuration the metric is quoted on, in full, through the command line program, and the 20 M triangle soup
+(cd pathtracer_amd && timeout -k 10 300 ./pathTracer --generate atrium --width 1920 --height 1080 --spp 1024 --stats --output /tmp/atrium.jpg) > $OUT/${TAG}_cli.log 2>&1 || echo "cli atrium failed"
+(cd pathtracer_amd && timeout -k 10 300 ./pathTracer --generate soup --spp 8 --stats --output /tmp/soup.jpg) > $OUT/${TAG}_cli_soup.log 2>&1 || echo "cli soup failed"
 tail -c 600 $OUT/${TAG}_bench_wide.json

@@ -18,4 +18,5 @@ for s in knot cornell soup; do for m in wide ordered reference; do
 done; done
 grep "^{" gpurun_out/${T}_other_configs.jsonl > profiles/${T}_other_configs.jsonl
 cp gpurun_out/${T}_valu_rate.txt profiles/
+for f in cli cli_soup; do [ -f gpurun_out/${T}_$f.log ] && grep -v amdgpu.ids gpurun_out/${T}_$f.log > profiles/${T}_$f.log; done
 python3 profiles/config_table.py $T
