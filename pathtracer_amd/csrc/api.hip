@@ -1428,6 +1428,7 @@ try
         pb.units = ( numPaths + kUnitPaths - 1 ) / kUnitPaths;
         HIP_TRY( hipMemsetAsync( s->cursors.ptr, 0, s->cursors.bytes, stream ) );
 
+        std::memcpy( pb.origin0, cam.position, sizeof( pb.origin0 ) );
         int span = timer.Begin( PT_K_RAYGEN );
         LaunchRaygen( cfg, cam, rng, pb, s->width, s->height, static_cast< uint32_t >( begin ), numPaths );
         timer.End( span );

@@ -961,9 +961,9 @@ __global__ __launch_bounds__( kBlock ) void RaygenKernel( CameraFrame cam, RngPa
         const float ju = r1 * ( 0.5f - -0.5f ) + -0.5f;
         f3 aa  = imagePlanePos + dU * ju + dV * jv;
         f3 dir = Normalize( aa - position );
-        pb.rayO[0][p] = F4( position, 0.0f ); // at bounce 0 the queue is the identity: entry = path id
+        // at bounce 0 the queue is the identity (entry = path id); the origin of every path is the camera and the throughput it
+        // starts with 1 (path_tracer.cpp:111, 189): the kernels that read them at bounce 0 know (PathBuffers::origin0)
         pb.rayD[0][p] = F4( dir, 0.0f );
-        pb.thr[0][p] = make_float4( 1.0f, 1.0f, 1.0f, 0.0f );
     }
 }
 
@@ -1182,7 +1182,7 @@ __global__ __launch_bounds__( kSpheres ? kTraverseBlock : kTriangleBlock ) __att
                 if ( idle && entry == kNoRay && rank < left )
                 {
                     entry = stream.base + stream.taken + rank;
-                    o   = F3( rayO[entry] );
+                    o   = bounce == 0 ? F3( pb.origin0[0], pb.origin0[1], pb.origin0[2] ) : F3( rayO[entry] );
                     d   = F3( rayD[entry] );
                     inv = F3( 1.0f / d.x, 1.0f / d.y, 1.0f / d.z ); // bvh.cpp:235-236
                     nx = inv.x < 0; ny = inv.y < 0; nz = inv.z < 0;
@@ -1300,7 +1300,8 @@ __global__ __launch_bounds__( kBlock ) void RedoKernel( SceneView sv, PathBuffer
     for ( uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < count; i += gridDim.x * kBlock )
     {
         const uint32_t entry = pb.redo[i];
-        const HitRecord h = RetraceInReferenceOrder( sv, sb, F3( pb.rayO[bounce & 1][entry] ), F3( pb.rayD[bounce & 1][entry] ), pb.hit[entry].x, cnt );
+        const f3 o = bounce == 0 ? F3( pb.origin0[0], pb.origin0[1], pb.origin0[2] ) : F3( pb.rayO[bounce & 1][entry] );
+        const HitRecord h = RetraceInReferenceOrder( sv, sb, o, F3( pb.rayD[bounce & 1][entry] ), pb.hit[entry].x, cnt );
         pb.hit[entry] = make_float4( h.t, h.u, h.v, __int_as_float( h.prim ) );
         rays++;
     }
@@ -1406,7 +1407,7 @@ void ExtendWideKernel( SceneView sv, PathBuffers pb, int bounce, uint32_t numPat
                 if ( idle && entry == kNoRay && rank < left )
                 {
                     entry = stream.base + stream.taken + rank;
-                    o   = F3( rayO[entry] );
+                    o   = bounce == 0 ? F3( pb.origin0[0], pb.origin0[1], pb.origin0[2] ) : F3( rayO[entry] );
                     d   = F3( rayD[entry] );
                     const f3 inv = F3( 1.0f / d.x, 1.0f / d.y, 1.0f / d.z ); // bvh.cpp:235-236
                     nx = inv.x < 0; ny = inv.y < 0; nz = inv.z < 0;
@@ -2013,7 +2014,7 @@ __global__ __launch_bounds__( kBlock ) void ShadeKernel( SceneView sv, RngParams
             const float4 hr = pb.hit[q];
             const int prim  = __float_as_int( hr.w );
             const f3 d = F3( pb.rayD[cur][q] );
-            T    = F3( pb.thr[cur][q] );
+            T    = bounce == 0 ? F3( 1.0f, 1.0f, 1.0f ) : F3( pb.thr[cur][q] ); // see RaygenKernel
             f3 L = F3( 0.0f, 0.0f, 0.0f ); // radiance so far: nothing at bounce 0; a hit at a later bounce does not touch it here
 
             if ( prim < 0 )
@@ -2024,7 +2025,7 @@ __global__ __launch_bounds__( kBlock ) void ShadeKernel( SceneView sv, RngParams
             }
             else
             {
-                const f3 o = F3( pb.rayO[cur][q] );
+                const f3 o = bounce == 0 ? F3( pb.origin0[0], pb.origin0[1], pb.origin0[2] ) : F3( pb.rayO[cur][q] );
                 const float t = hr.x, u = hr.y, v = hr.z;
                 sf.position = o + d * t; // Ray::Evaluate
                 float tu, tv;
@@ -2254,7 +2255,7 @@ __global__ __launch_bounds__( kBlock ) void ResolveKernel( SceneView sv, PathBuf
             }
             Ldirect = Ldirect + Ld / static_cast< float >( nSamples );
         }
-        const f3 T = F3( pb.thr[cur][q] );
+        const f3 T = bounce == 0 ? F3( 1.0f, 1.0f, 1.0f ) : F3( pb.thr[cur][q] ); // see RaygenKernel
         f3 L       = F3( pb.rad[p] );
         pb.rad[p]  = F4( L + T * Ldirect, 0.0f );
     }

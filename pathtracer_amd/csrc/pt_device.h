@@ -142,6 +142,7 @@ struct PathBuffers
     uint32_t units;         // units of kUnitPaths consecutive path ids in this pass
     uint32_t shadowSlots;   // shadow records per path, at least 1
     uint32_t directSum;     // 1: one light with one sample - ConnectKernel adds the direct light itself, no ResolveKernel
+    float origin0[3];       // where every ray of bounce 0 starts (the camera): not stored per path, like the throughput 1 they start with
 };
 
 // Paths per unit of work; every queue has one segment of this many entries (times shadowSlots for shadowRays) per unit
