@@ -247,3 +247,22 @@ def test_command_line_program_from_a_scene_file(tmp_path):
     camera = scene._desc.camera
     host.write_image(str(tmp_path / "mirror_exact.png"), host.tonemap(tracer.linearImage, camera.exposure, camera.gamma, 0))
     assert (tmp_path / "mirror_exact.png").read_bytes() == (tmp_path / "run2" / "exact.png").read_bytes()
+
+
+def test_command_line_traversal_switches_save_the_same_picture(tmp_path):
+    """The command line program on a scene large enough for its default - the eight-wide layout for closest-hit and
+    shadow rays - against `--binary-tree` (front to back over the binary tree) and `--reference-order`: the three
+    saved pictures are the same file, the counters differ as they should."""
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "pathtracer_amd", "pathTracer")
+    files, visits = {}, {}
+    for name, extra in (("wide", []), ("binary", ["--binary-tree"]), ("reference", ["--reference-order"])):
+        r = subprocess.run([exe, "--generate", "atrium", "--triangles", "60000", "--width", "320", "--height", "180", "--spp", "6", "--seed", "3",
+                            "--stats", "--output", f"{name}.png"] + extra, capture_output=True, text=True, cwd=tmp_path, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        files[name] = (tmp_path / f"{name}.png").read_bytes()
+        visits[name] = float(re.search(r"nodes per ray ([0-9.]+)", r.stdout).group(1))
+    assert files["wide"] == files["reference"] and files["binary"] == files["reference"]
+    assert visits["wide"] < 0.5 * visits["binary"] < 0.5 * visits["reference"] * 1.01
