@@ -1311,8 +1311,9 @@ __global__ __launch_bounds__( kBlock ) void RedoKernel( SceneView sv, PathBuffer
     FlushCounter( stats, ST_SPH_CLOSEST, cnt.spheres );
 }
 
-// ExtendKernel over the wide layout (see "wide nodes" above): the same wave-level scheduling - refill, leaf phase,
-// bursts of node visits - with a short stack per lane.  The first kWideLdsStack entries of a lane's stack live in LDS
+// ExtendKernel over the wide layout (see "wide nodes" above): the same wave-level scheduling - refill, primitive tests,
+// bursts of node visits - with a short stack per lane, and with the primitive tests put off: a lane that has found leaf
+// children keeps them in a short list and goes on visiting nodes (see leafLds).  The first kWideLdsStack entries of a lane's stack live in LDS
 // (entry-major, so that the lanes of a wave touch consecutive words), deeper ones in `spill`, one slot per thread of
 // the grid and level; the tree's depth bounds the stack, because a level pushes at most one entry.  Results and the
 // queue of rays to trace again are ExtendKernel< ., true >'s.
@@ -1334,24 +1335,38 @@ __global__ __launch_bounds__( kBlock ) void RedoKernel( SceneView sv, PathBuffer
 #ifndef PT_WIDE_REFILL_LANES
 #define PT_WIDE_REFILL_LANES 24
 #endif
-#ifndef PT_WIDE_LEAF_LANES
-#define PT_WIDE_LEAF_LANES 16
-#endif
 #ifndef PT_WIDE_BURST
 #define PT_WIDE_BURST 2
 #endif
-// the same three for the any-hit kernel over the wide layout
+// refill, start of the primitive tests (lanes with untested leaf children) and burst length of the any-hit kernel over the
+// wide layout; PT_WIDE_SHADOW_DEFERRED / PT_WIDE_SHADOW_KEEP_LANES below are its list length and stop threshold (list of
+// 1 / 2 / 3: 13.10 / 13.06 / 13.46 ms per launch; start at 16 / 20 / 28 / 36: 13.22 / 13.06 / 13.22 / 13.60; testing at once: 13.7)
 #ifndef PT_WIDE_SHADOW_REFILL_LANES
 #define PT_WIDE_SHADOW_REFILL_LANES 24
 #endif
 #ifndef PT_WIDE_SHADOW_LEAF_LANES
-#define PT_WIDE_SHADOW_LEAF_LANES 28
+#define PT_WIDE_SHADOW_LEAF_LANES 20
 #endif
 #ifndef PT_WIDE_SHADOW_BURST
 #define PT_WIDE_SHADOW_BURST 2
 #endif
 constexpr int kWideBlock = PT_WIDE_BLOCK, kWideSphereBlock = PT_WIDE_SPHERE_BLOCK;
 constexpr uint32_t kWideLdsStack = PT_WIDE_LDS_STACK;
+
+// The list of leaf children a lane has found and not tested yet (see leafLds in ExtendWideKernel): its length, the lanes
+// with a non-empty list at which the wave starts testing primitives, and at which it stops again.  Measured on a
+// Sponza-class scene, closest-hit launch: list of 1 / 2 / 3 / 4: 30.3 / 28.9 / 29.1 / 29.6 ms (testing at once, as the kernel
+// did before: 31.7); start at 12 / 16 / 20 / 24 / 32 lanes: 29.6 / 29.0 / 28.9 / 29.7 / 31.0; stop at 8 / 12 / 16: 29.2 / 28.9 / 29.0.
+#ifndef PT_WIDE_DEFERRED
+#define PT_WIDE_DEFERRED 2
+#endif
+#ifndef PT_WIDE_DEFER_LEAF_LANES
+#define PT_WIDE_DEFER_LEAF_LANES 20
+#endif
+#ifndef PT_WIDE_DEFER_KEEP_LANES
+#define PT_WIDE_DEFER_KEEP_LANES 12
+#endif
+constexpr uint32_t kWideDeferred = PT_WIDE_DEFERRED;
 
 template < bool kSpheres >
 __global__ __launch_bounds__( kSpheres ? kWideSphereBlock : kWideBlock ) __attribute__( ( amdgpu_waves_per_eu( kSpheres ? PT_WIDE_SPHERE_WAVES : PT_WIDE_WAVES, kSpheres ? PT_WIDE_SPHERE_WAVES : PT_WIDE_WAVES ) ) )
@@ -1366,22 +1381,26 @@ void ExtendWideKernel( SceneView sv, PathBuffers pb, int bounce, uint32_t numPat
     // the first kWideLdsStack of them in LDS, entry-major
     __shared__ uint2 stackLds[kWideLdsStack * kThreads];
     uint2* const myLds = stackLds + threadIdx.x;
+    // Primitive tests can wait: they only ever shrink the distance that culls.  A lane keeps the leaf children it has found
+    // and not tested yet - per node { first leaf primitive, leaf slots << 8 | hit slots left } - in a short list and goes on
+    // visiting nodes; the wave tests primitives when enough lanes have some, for as long as enough lanes have some.
+    __shared__ uint2 leafLds[kWideDeferred * kThreads];
+    uint2* const myLeaves = leafLds + threadIdx.x;
+    uint32_t numLeaves = 0; // groups in the list
     const size_t spillStride = static_cast< size_t >( gridDim.x ) * kThreads, spillLane = static_cast< size_t >( blockIdx.x ) * kThreads + threadIdx.x;
     uint32_t entry = kNoRay;
     f3 o = F3( 0.0f, 0.0f, 0.0f ), d = o, invW = o; // invW: WideInv of the reciprocal direction
     bool nx = false, ny = false, nz = false;
     uint32_t sp = 0;
-    uint32_t primBase = 0, leafBits = 0; // of the node visited last: its leaf slots << 8 | those of them hit and not tested yet
     uint32_t ambiguous = 0;
     HitRecord h{ FLT_MAX, 0.0f, 0.0f, -1 };
     uint32_t waveRays = 0, waveNodes = 0, waveTris = 0, waveSpheres = 0, waveSteps = 0; // whole-wave totals, wave-uniform
 
     for ( ;; )
     {
-        const bool atLeaf = ( leafBits & 0xFFu ) != 0;
-        const bool idle   = ( ( leafBits & 0xFFu ) | sp ) == 0;
-        const unsigned long long mLeaf = Ballot( atLeaf ), mIdle = Ballot( idle );
-        const unsigned long long mTrav = ~mIdle & ~mLeaf;
+        const bool idle = ( numLeaves | sp ) == 0;
+        const unsigned long long mLeaf = Ballot( numLeaves != 0 ), mIdle = Ballot( idle );
+        const unsigned long long mTrav = Ballot( sp != 0 ) & Ballot( numLeaves < kWideDeferred );
         const unsigned long long mRay  = mIdle & ( stream.ended ? Ballot( entry != kNoRay ) : ~0ull );
         if ( ( mLeaf | mTrav | mRay ) == 0 ) break;
 
@@ -1414,7 +1433,6 @@ void ExtendWideKernel( SceneView sv, PathBuffers pb, int bounce, uint32_t numPat
                     invW      = WideInv( inv );
                     h         = HitRecord{ FLT_MAX, 0.0f, 0.0f, -1 };     // scene.cpp:372
                     ambiguous = WideDegenerate( inv ) ? kUntrusted : 0u;  // such a ray goes straight to the second pass
-                    leafBits  = 0;
                     sp        = ambiguous ? 0u : 1u;
                     myLds[0]  = make_uint2( 0u, 0x0101u );                // the root as the one child of a node above it
                 }
@@ -1425,35 +1443,38 @@ void ExtendWideKernel( SceneView sv, PathBuffers pb, int bounce, uint32_t numPat
             continue;
         }
 
-        if ( mLeaf && ( __popcll( mLeaf ) >= PT_WIDE_LEAF_LANES || mTrav == 0 ) )
+        if ( mLeaf && ( __popcll( mLeaf ) >= PT_WIDE_DEFER_LEAF_LANES || mTrav == 0 ) )
         {
-            for ( ;; )
+            do
             {
-                const uint32_t l = leafBits & 0xFFu;
-                if ( Ballot( l != 0 ) == 0 ) break;
                 bool isTri = false, isSphere = false;
-                if ( l != 0 )
+                if ( numLeaves != 0 )
                 {
-                    const uint32_t k = static_cast< uint32_t >( __builtin_ctz( l ) );
-                    leafBits &= ~( 1u << k );
+                    uint2 g = myLeaves[( numLeaves - 1u ) * kThreads];
+                    const uint32_t k = static_cast< uint32_t >( __builtin_ctz( g.y & 0xFFu ) );
+                    g.y &= ~( 1u << k );
+                    if ( ( g.y & 0xFFu ) == 0 )
+                        numLeaves--;
+                    else
+                        myLeaves[( numLeaves - 1u ) * kThreads].y = g.y;
                     // the reciprocal direction itself, for the reference's box test: invW but for the infinities it replaced
                     // (a ray with a component WideInv takes out never gets here)
                     const f3 inv = F3( fabsf( invW.x ) == kWideInvLimit ? __builtin_copysignf( INFINITY, invW.x ) : invW.x,
                                        fabsf( invW.y ) == kWideInvLimit ? __builtin_copysignf( INFINITY, invW.y ) : invW.y,
                                        fabsf( invW.z ) == kWideInvLimit ? __builtin_copysignf( INFINITY, invW.z ) : invW.z );
-                    ClosestPrimTestWide< kSpheres >( sv, sb.prims, primBase + __popc( ( leafBits >> 8 ) & ( ( 1u << k ) - 1u ) ), o, d, inv, nx, ny, nz, h, &isSphere, &ambiguous );
+                    ClosestPrimTestWide< kSpheres >( sv, sb.prims, g.x + __popc( ( g.y >> 8 ) & ( ( 1u << k ) - 1u ) ), o, d, inv, nx, ny, nz, h, &isSphere, &ambiguous );
                     isTri = !isSphere;
                 }
                 waveTris += LanesSet( isTri );
                 waveSpheres += LanesSet( isSphere );
-            }
+            } while ( LanesSet( numLeaves != 0 ) >= PT_WIDE_DEFER_KEEP_LANES );
             continue;
         }
 
         const uint32_t started = static_cast< uint32_t >( __popcll( mTrav ) );
         for ( int burst = 0; burst < PT_WIDE_BURST; ++burst )
         {
-            const bool go = ( leafBits & 0xFFu ) == 0 && sp != 0;
+            const bool go = sp != 0 && numLeaves < kWideDeferred;
             const uint32_t active = LanesSet( go );
             if ( burst && 2 * active < started ) break;
             waveNodes += active;
@@ -1476,8 +1497,7 @@ void ExtendWideKernel( SceneView sv, PathBuffers pb, int bounce, uint32_t numPat
                 else
                     spill[( top - kWideLdsStack ) * spillStride + spillLane].y = left;
                 const WideGroup g = WideVisit< kSpheres >( sb.nodes, e.x + __popc( ( e.y >> 8 ) & ( ( 1u << s ) - 1u ) ), o, invW, nx, ny, nz, h.t * kBand );
-                primBase = g.primBase;
-                leafBits = g.bits >> 16;
+                if ( g.bits & 0xFF0000u ) myLeaves[numLeaves++ * kThreads] = make_uint2( g.primBase, g.bits >> 16 );
                 if ( g.bits & 0xFFu )
                 {
                     if ( sp < kWideLdsStack )
@@ -1647,6 +1667,14 @@ __global__ __launch_bounds__( kConnectBlock ) PT_CONNECT_OCCUPANCY void ConnectK
 // ConnectKernel over the wide layout: any hit, with ExtendWideKernel's stack and scheduling.  The order of the search
 // does not matter to the answer: a primitive counts only if the reference's own test of its leaf box against the ray's
 // fixed tMax passes (AnyPrimTestWide), which is the condition under which BVH::Occluded reaches it.
+#ifndef PT_WIDE_SHADOW_DEFERRED
+#define PT_WIDE_SHADOW_DEFERRED 2
+#endif
+#ifndef PT_WIDE_SHADOW_KEEP_LANES
+#define PT_WIDE_SHADOW_KEEP_LANES 12
+#endif
+constexpr uint32_t kWideShadowDeferred = PT_WIDE_SHADOW_DEFERRED;
+
 template < bool kDirectSum >
 __global__ __launch_bounds__( kWideBlock ) __attribute__( ( amdgpu_waves_per_eu( PT_WIDE_WAVES, PT_WIDE_WAVES ) ) )
 void ConnectWideKernel( SceneView sv, PathBuffers pb, int bounce, uint2* spill, uint64_t* stats )
@@ -1657,20 +1685,22 @@ void ConnectWideKernel( SceneView sv, PathBuffers pb, int bounce, uint2* spill, 
     const SceneBuffers sb  = MakeWideBuffers( sv );
     __shared__ uint2 stackLds[kWideLdsStack * kThreads];
     uint2* const myLds = stackLds + threadIdx.x;
+    __shared__ uint2 leafLds[kWideShadowDeferred * kThreads]; // leaf children found and not tested yet, as in ExtendWideKernel
+    uint2* const myLeaves = leafLds + threadIdx.x;
+    uint32_t numLeaves = 0;
     const size_t spillStride = static_cast< size_t >( gridDim.x ) * kThreads, spillLane = static_cast< size_t >( blockIdx.x ) * kThreads + threadIdx.x;
     uint32_t rec = kNoRay;
     f3 o = F3( 0.0f, 0.0f, 0.0f ), d = o, inv = o, invW = o;
     float tMax = 0.0f;
     bool nx = false, ny = false, nz = false, occluded = false;
-    uint32_t sp = 0, primBase = 0, leafBits = 0;
+    uint32_t sp = 0;
     uint32_t waveRays = 0, waveNodes = 0, waveTris = 0, waveSpheres = 0, waveSteps = 0; // whole-wave totals, wave-uniform
 
     for ( ;; )
     {
-        const bool atLeaf = ( leafBits & 0xFFu ) != 0;
-        const bool idle   = ( ( leafBits & 0xFFu ) | sp ) == 0;
-        const unsigned long long mLeaf = Ballot( atLeaf ), mIdle = Ballot( idle );
-        const unsigned long long mTrav = ~mIdle & ~mLeaf;
+        const bool idle = ( numLeaves | sp ) == 0;
+        const unsigned long long mLeaf = Ballot( numLeaves != 0 ), mIdle = Ballot( idle );
+        const unsigned long long mTrav = Ballot( sp != 0 ) & Ballot( numLeaves < kWideShadowDeferred );
         const unsigned long long mRay  = mIdle & ( stream.ended ? Ballot( rec != kNoRay ) : ~0ull );
         if ( ( mLeaf | mTrav | mRay ) == 0 ) break;
 
@@ -1713,7 +1743,6 @@ void ConnectWideKernel( SceneView sv, PathBuffers pb, int bounce, uint2* spill, 
                     inv  = F3( 1.0f / d.x, 1.0f / d.y, 1.0f / d.z ); // bvh.cpp:275-276
                     nx = inv.x < 0; ny = inv.y < 0; nz = inv.z < 0;
                     invW     = WideInv( inv );
-                    leafBits = 0;
                     occluded = false;
                     sp       = 1u;
                     myLds[0] = make_uint2( 0u, 0x0101u ); // the root as the one child of a node above it
@@ -1727,33 +1756,36 @@ void ConnectWideKernel( SceneView sv, PathBuffers pb, int bounce, uint2* spill, 
 
         if ( mLeaf && ( __popcll( mLeaf ) >= PT_WIDE_SHADOW_LEAF_LANES || mTrav == 0 ) )
         {
-            for ( ;; )
+            do
             {
-                const uint32_t l = leafBits & 0xFFu;
-                if ( Ballot( l != 0 ) == 0 ) break;
                 bool isTri = false, isSphere = false;
-                if ( l != 0 )
+                if ( numLeaves != 0 )
                 {
-                    const uint32_t k = static_cast< uint32_t >( __builtin_ctz( l ) );
-                    leafBits &= ~( 1u << k );
-                    if ( AnyPrimTestWide( sb.prims, primBase + __popc( ( leafBits >> 8 ) & ( ( 1u << k ) - 1u ) ), o, d, inv, nx, ny, nz, tMax, &isSphere ) )
+                    uint2 g = myLeaves[( numLeaves - 1u ) * kThreads];
+                    const uint32_t k = static_cast< uint32_t >( __builtin_ctz( g.y & 0xFFu ) );
+                    g.y &= ~( 1u << k );
+                    if ( ( g.y & 0xFFu ) == 0 )
+                        numLeaves--;
+                    else
+                        myLeaves[( numLeaves - 1u ) * kThreads].y = g.y;
+                    if ( AnyPrimTestWide( sb.prims, g.x + __popc( ( g.y >> 8 ) & ( ( 1u << k ) - 1u ) ), o, d, inv, nx, ny, nz, tMax, &isSphere ) )
                     {
-                        occluded = true; // bvh.cpp:287-293: stop at the first hit
-                        leafBits = 0;
-                        sp       = 0;
+                        occluded  = true; // bvh.cpp:287-293: stop at the first hit
+                        numLeaves = 0;
+                        sp        = 0;
                     }
                     isTri = !isSphere;
                 }
                 waveTris += LanesSet( isTri );
                 waveSpheres += LanesSet( isSphere );
-            }
+            } while ( LanesSet( numLeaves != 0 ) >= PT_WIDE_SHADOW_KEEP_LANES );
             continue;
         }
 
         const uint32_t started = static_cast< uint32_t >( __popcll( mTrav ) );
         for ( int burst = 0; burst < PT_WIDE_SHADOW_BURST; ++burst )
         {
-            const bool go = ( leafBits & 0xFFu ) == 0 && sp != 0;
+            const bool go = sp != 0 && numLeaves < kWideShadowDeferred;
             const uint32_t active = LanesSet( go );
             if ( burst && 2 * active < started ) break;
             waveNodes += active;
@@ -1775,8 +1807,7 @@ void ConnectWideKernel( SceneView sv, PathBuffers pb, int bounce, uint2* spill, 
                 else
                     spill[( top - kWideLdsStack ) * spillStride + spillLane].y = left;
                 const WideGroup g = WideVisit< false >( sb.nodes, e.x + __popc( ( e.y >> 8 ) & ( ( 1u << s ) - 1u ) ), o, invW, nx, ny, nz, tMax );
-                primBase = g.primBase;
-                leafBits = g.bits >> 16;
+                if ( g.bits & 0xFF0000u ) myLeaves[numLeaves++ * kThreads] = make_uint2( g.primBase, g.bits >> 16 );
                 if ( g.bits & 0xFFu )
                 {
                     if ( sp < kWideLdsStack )
