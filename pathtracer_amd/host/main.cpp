@@ -177,8 +177,9 @@ public:
                 int rc = pt_render( m_scenes[g], &params );
                 if ( rc == PT_ERR_STATE && ( params.flags & PT_RENDER_WIDE ) )
                 {
-                    // a tree the eight-wide layout cannot express: front to back over the tree itself
-                    params.flags = ( params.flags & ~static_cast< uint32_t >( PT_RENDER_WIDE | PT_RENDER_WIDE_SHADOWS ) ) | PT_RENDER_ORDERED;
+                    // a tree the eight-wide layout cannot express: front to back over the tree itself (a small one: in the reference's order)
+                    const bool small = !( params.flags & PT_RENDER_WIDE_SHADOWS );
+                    params.flags = ( params.flags & ~static_cast< uint32_t >( PT_RENDER_WIDE | PT_RENDER_WIDE_SHADOWS ) ) | ( small ? 0u : PT_RENDER_ORDERED );
                     rc           = pt_render( m_scenes[g], &params );
                 }
                 if ( rc != PT_OK ) errors[g] = pt_last_error(); // the message is per thread
@@ -342,11 +343,11 @@ int main( int argc, char** argv )
     // Perform all the renderings ("SamplesPerPixel": [ 8, 32, ... ]), src/main.cpp:30-49
     for ( size_t it = 0; it < sppList.size(); ++it )
     {
-        // over the eight-wide layout (closest hits and shadow rays) unless asked otherwise - or the tree is so small that the
-        // binary-tree kernels' LDS copy holds it whole, where the reference's order is the fastest (same picture either way)
+        // over the eight-wide layout unless asked otherwise: closest hits always, shadow rays unless the tree is so small that
+        // the binary-tree kernels' LDS copy holds it whole, where they are faster over that (same picture either way)
         uint32_t renderFlags = 0;
         if ( opt.binaryTree && !opt.referenceOrder ) renderFlags = PT_RENDER_ORDERED;
-        else if ( !opt.referenceOrder && desc.num_nodes > 2400 ) renderFlags = PT_RENDER_WIDE | PT_RENDER_WIDE_SHADOWS;
+        else if ( !opt.referenceOrder ) renderFlags = desc.num_nodes > 2400 ? PT_RENDER_WIDE | PT_RENDER_WIDE_SHADOWS : PT_RENDER_WIDE;
         PathTracer pathTracer( gpuScenes, desc.image_width, desc.image_height, desc.camera, opt.hostTonemap, renderFlags );
         PtStats stats{};
         const uint64_t seed = opt.haveSeed ? opt.seed : ( static_cast< uint64_t >( entropy() ) << 32 | entropy() );

@@ -65,8 +65,9 @@ def sample_range(spp, rank, world_size):
 
 
 class PathTracer:
-    # A tree this small sits whole in the LDS copy the binary-tree kernels keep; the reference's order is then the fastest
-    # (Cornell box, closest-hit traversal of 256 samples per pixel: 66.7 ms, front to back 70.9, eight-wide layout 69.8)
+    # A tree this small sits whole in the LDS copy the binary-tree kernels keep: its shadow rays are then fastest over the
+    # binary tree (Cornell box, 256 samples per pixel: 67.9 ms against 69.4 over the eight-wide layout), its closest hits over
+    # the eight-wide layout all the same (49.7 ms against 55.4 in the reference's order and 62.3 front to back)
     SMALL_TREE_NODES = 2400
 
     def __init__(self, device=0, seed=0, tonemap=abi.PT_TONEMAP_UNCHARTED2, ordered=None, traversal=None):
@@ -99,8 +100,16 @@ class PathTracer:
         except ImportError:
             pass
         begin, end = sample_range(spp, rank, world)
-        traversal = self.traversal or ("wide" if scene._desc.num_nodes > self.SMALL_TREE_NODES else "reference")
-        dev.render(spp, begin, end, seed=self.seed, ordered=traversal != "reference", wide=traversal == "wide", wide_shadows=traversal == "wide")
+        traversal = self.traversal or "wide"
+        wide_shadows = traversal == "wide" and (self.traversal == "wide" or scene._desc.num_nodes > self.SMALL_TREE_NODES)
+        try:
+            dev.render(spp, begin, end, seed=self.seed, ordered=traversal != "reference", wide=traversal == "wide", wide_shadows=wide_shadows)
+        except api.PtError as e:
+            if self.traversal is not None or e.code != abi.PT_ERR_STATE:
+                raise
+            # a tree the eight-wide layout cannot express (a box that is not finite or lies outside its parent's)
+            small = scene._desc.num_nodes <= self.SMALL_TREE_NODES
+            dev.render(spp, begin, end, seed=self.seed, ordered=not small)
         if world > 1:
             reduce_film(dev, self.device, dist, process_group)
             if rank != 0:
