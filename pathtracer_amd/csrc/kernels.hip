@@ -1289,6 +1289,12 @@ __global__ __launch_bounds__( kSpheres ? kTraverseBlock : kTriangleBlock ) __att
     FlushWaveCounter( stats, ST_STEPS_CLOSEST, waveSteps );
 }
 
+// Blocks of RedoKernel's grid.  How many rays there are is known on the device only; a thread takes every gridth of them, one
+// after the other, each a chain of dependent fetches - so the grid is as large as the longest queue seen (a million
+// threads; the ones without a ray leave at once)
+#ifndef PT_REDO_BLOCKS
+#define PT_REDO_BLOCKS 4096
+#endif
 // The rays ExtendKernel< ., true > found ambiguous, traced again in the reference's order (BVH::Intersect,
 // src/bvh.cpp:230-268) over the reference-order layout: one thread per ray, the result replaces the first one.
 __global__ __launch_bounds__( kBlock ) void RedoKernel( SceneView sv, PathBuffers pb, int bounce, uint64_t* stats )
@@ -2482,7 +2488,7 @@ void LaunchExtend( const LaunchCfg& cfg, const SceneView& sv, const PathBuffers&
             hipLaunchKernelGGL( ( ExtendWideKernel< true > ), dim3( cfg.wideBlocks ), dim3( kWideSphereBlock ), 0, cfg.stream, sv, pb, bounce, numPaths, cfg.wideSpill, stats );
         else
             hipLaunchKernelGGL( ( ExtendWideKernel< false > ), dim3( cfg.wideBlocks ), dim3( kWideBlock ), 0, cfg.stream, sv, pb, bounce, numPaths, cfg.wideSpill, stats );
-        hipLaunchKernelGGL( RedoKernel, dim3( cfg.blocks > 256 ? cfg.blocks : 256 ), dim3( kBlock ), 0, cfg.stream, sv, pb, bounce, stats );
+        hipLaunchKernelGGL( RedoKernel, dim3( PT_REDO_BLOCKS ), dim3( kBlock ), 0, cfg.stream, sv, pb, bounce, stats );
         return;
     }
     const dim3 grid( cfg.extendBlocks ), block( sv.numSpheres ? kTraverseBlock : kTriangleBlock );
@@ -2495,7 +2501,7 @@ void LaunchExtend( const LaunchCfg& cfg, const SceneView& sv, const PathBuffers&
     else
         hipLaunchKernelGGL( ( ExtendKernel< false, false > ), grid, block, 0, cfg.stream, sv, pb, bounce, numPaths, stats );
     // one thread per ambiguous ray where the grid reaches (its length is known on the device only); a thread's rays run one after the other
-    if ( cfg.ordered ) hipLaunchKernelGGL( RedoKernel, dim3( cfg.blocks > 256 ? cfg.blocks : 256 ), dim3( kBlock ), 0, cfg.stream, sv, pb, bounce, stats );
+    if ( cfg.ordered ) hipLaunchKernelGGL( RedoKernel, dim3( PT_REDO_BLOCKS ), dim3( kBlock ), 0, cfg.stream, sv, pb, bounce, stats );
 }
 
 void LaunchShade( const LaunchCfg& cfg, const SceneView& sv, const RngParams& rng, const PathBuffers& pb, int bounce, int maxDepth,
