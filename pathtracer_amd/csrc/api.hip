@@ -487,6 +487,7 @@ int Upload( PtScene* s, const PtSceneDesc* d, const std::vector< uint32_t >& esc
 
     // the description on the device, for the kernels that write the records; released when the upload returns
     DeviceBuffer rawNodes, rawEscape, rawPrims, rawTriangles, rawMeshes, rawVertices, rawNormals, rawTangents, rawUvs, rawSpheres, rawSphereBelow;
+    DeviceBuffer dTopSorted, dTopRank; // the top of the tree by reference index, and where each of its nodes is stored
     LayoutInputs in;
     if ( !hostLayouts )
     {
@@ -518,13 +519,11 @@ int Upload( PtScene* s, const PtSceneDesc* d, const std::vector< uint32_t >& esc
             topSorted[k] = topByIndex[k].first;
             topRank[k]   = topByIndex[k].second;
         }
-        DeviceBuffer dTopSorted, dTopRank;
         HIP_TRY( dTopSorted.Upload( topSorted.data(), 4 * topSorted.size() ) );
         HIP_TRY( dTopRank.Upload( topRank.data(), 4 * topRank.size() ) );
         HIP_TRY( s->nodes.Allocate( 32ull * N ) );
         BuildReferenceNodes( nullptr, in, dTopSorted.As< uint32_t >(), dTopRank.As< uint32_t >(), static_cast< uint32_t >( bfs.size() ), s->nodes.As< float4 >() );
         HIP_TRY( hipGetLastError() );
-        HIP_TRY( hipDeviceSynchronize() ); // the two small buffers go out of scope here
     }
     else
     {
@@ -721,7 +720,9 @@ int Upload( PtScene* s, const PtSceneDesc* d, const std::vector< uint32_t >& esc
         // Bounds of every node in the light's frame, from the geometry below it rather than from its box (the rectangle
         // around a box seen at an angle is far larger than the one around its triangles): leaves from their primitives,
         // inner nodes from their children, children before parents.  {u0, u1, v0, v1} per node, rounded outwards.
-        std::unique_ptr< float[] > frame( build ? new float[4ull * N] : nullptr );
+        std::unique_ptr< float[] > frame( build && hostLayouts ? new float[4ull * N] : nullptr );
+        DeviceBuffer dFrame;
+        float rootFrame[4] = { 0, 0, 0, 0 };
         auto down = []( double x ) { float f = static_cast< float >( x ); return static_cast< double >( f ) > x ? std::nextafter( f, -std::numeric_limits< float >::infinity() ) : f; };
         auto up   = []( double x ) { float f = static_cast< float >( x ); return static_cast< double >( f ) < x ? std::nextafter( f, std::numeric_limits< float >::infinity() ) : f; };
         auto bound = [&]( uint32_t i ) {
@@ -771,20 +772,37 @@ int Upload( PtScene* s, const PtSceneDesc* d, const std::vector< uint32_t >& esc
             f[0] = down( lo[0] ); f[1] = up( hi[0] );
             f[2] = down( lo[1] ); f[3] = up( hi[1] );
         };
-        if ( build )
+        if ( build && !hostLayouts )
+        {
+            DeviceBuffer dParent, dArrivals;
+            ShadowAxes axes;
+            for ( int a = 0; a < 3; ++a )
+            {
+                axes.u[a] = fu[a];
+                axes.v[a] = fv[a];
+            }
+            HIP_TRY( dFrame.Allocate( 16ull * N ) );
+            HIP_TRY( dParent.Allocate( 4ull * N ) );
+            HIP_TRY( dArrivals.Allocate( 4ull * N ) );
+            BuildShadowFrames( nullptr, in, axes, dParent.As< uint32_t >(), dArrivals.As< uint32_t >(), dFrame.As< float >() );
+            HIP_TRY( hipGetLastError() );
+            HIP_TRY( hipMemcpy( rootFrame, dFrame.ptr, 16, hipMemcpyDeviceToHost ) );
+        }
+        else if ( build )
         {
             const TreeCut cut = CutTree( d, escape );
             ForEachSubtree( cut, N, [&]( uint32_t root ) {
                 for ( uint32_t i = escape[root]; i-- > root; ) bound( i );
             } );
             for ( size_t k = cut.upper.size(); k-- > 0; ) bound( cut.upper[k] );
+            std::memcpy( rootFrame, frame.get(), 16 );
         }
         double origin[2] = { 0, 0 }, cell[2] = { 1, 1 };
         float invCell[2] = { 1, 1 }, originF[2] = { 0, 0 };
         double slack[2] = { 1, 1 }; // in cells
         for ( int a = 0; a < 2 && build; ++a )
         {
-            const double lo = frame[2 * a], hi = frame[2 * a + 1]; // the root's
+            const double lo = rootFrame[2 * a], hi = rootFrame[2 * a + 1];
             build = std::isfinite( lo ) && std::isfinite( hi );
             if ( !build ) break;
             cell[a]    = std::max( { ( hi - lo ) / 64000.0, std::ldexp( maxAbs, -18 ), 1e-30 } );
@@ -801,10 +819,39 @@ int Upload( PtScene* s, const PtSceneDesc* d, const std::vector< uint32_t >& esc
             origin[a]  = originF[a];
             build      = std::isfinite( originF[a] ) && std::isfinite( invCell[a] ) && ( hi - origin[a] ) / cell[a] + border < 65534.0;
         }
-        if ( build )
+        if ( build ) shadowTop = static_cast< uint32_t >( std::min< size_t >( bfs.size(), kShadowTopNodes ) );
+        if ( build && !hostLayouts )
+        {
+            DeviceBuffer dBefore, dBlockSums;
+            HIP_TRY( dBefore.Allocate( 4ull * ( N + 1 ) ) );
+            HIP_TRY( dBlockSums.Allocate( 4ull * ( LayoutScanBlocks( N ) + 1 ) ) );
+            CountShadowRecords( nullptr, in, dTopSorted.As< uint32_t >(), dTopRank.As< uint32_t >(), static_cast< uint32_t >( bfs.size() ), shadowTop,
+                                dBefore.As< uint32_t >(), dBlockSums.As< uint32_t >() );
+            HIP_TRY( hipGetLastError() );
+            uint32_t behindTheTop = 0;
+            HIP_TRY( hipMemcpy( &behindTheTop, dBefore.As< uint32_t >() + N, 4, hipMemcpyDeviceToHost ) );
+            numShadow = shadowTop + behindTheTop;
+            ShadowGrid grid;
+            for ( int a = 0; a < 2; ++a )
+            {
+                grid.origin[a] = origin[a];
+                grid.cell[a]   = cell[a];
+                grid.slack[a]  = slack[a];
+            }
+            grid.depthAxis       = static_cast< uint32_t >( depthAxis );
+            grid.towardsPositive = w[depthAxis] > 0;
+            grid.shadowTop       = shadowTop;
+            grid.numRecords      = numShadow;
+            HIP_TRY( s->shadowNodes.Allocate( 16ull * numShadow ) );
+            HIP_TRY( s->shadowTopWords.Allocate( 4ull * shadowTop ) );
+            BuildShadowRecords( nullptr, in, dFrame.As< float >(), grid, dTopSorted.As< uint32_t >(), dTopRank.As< uint32_t >(), static_cast< uint32_t >( bfs.size() ),
+                                dBefore.As< uint32_t >(), s->shadowNodes.As< uint4 >(), s->shadowTopWords.As< uint32_t >() );
+            HIP_TRY( hipGetLastError() );
+            HIP_TRY( hipDeviceSynchronize() ); // the scratch buffers go out of scope here
+        }
+        else if ( build )
         {
             const uint32_t unset = 0xFFFFFFFFu;
-            shadowTop = static_cast< uint32_t >( std::min< size_t >( bfs.size(), kShadowTopNodes ) );
             std::vector< uint32_t > sp( N + 1, unset ); // reference index -> record
             for ( uint32_t k = 0; k < shadowTop; ++k ) sp[bfs[k]] = k;
             std::vector< std::pair< uint32_t, uint32_t > > jumps; // (record, reference index of its target)
@@ -857,6 +904,9 @@ int Upload( PtScene* s, const PtSceneDesc* d, const std::vector< uint32_t >& esc
             }
             HIP_TRY( s->shadowNodes.Upload( rec.get(), 16ull * numShadow ) );
             HIP_TRY( s->shadowTopWords.Upload( topWords.data(), 4ull * shadowTop ) );
+        }
+        if ( build )
+        {
             for ( int a = 0; a < 3; ++a )
             {
                 s->view.lightU[a] = fu[a];
@@ -1535,7 +1585,7 @@ int pt_read_layout( PtScene* s, uint32_t which, void* dst, uint64_t capacity, ui
 try
 {
     if ( !s ) return Fail( PT_ERR_INVALID_ARG, "pt_read_layout: null scene" );
-    const DeviceBuffer* all[] = { &s->nodes, &s->orderedNodes, &s->prims, &s->triShade, &s->wideNodes, &s->widePrims, &s->shadowNodes };
+    const DeviceBuffer* all[] = { &s->nodes, &s->orderedNodes, &s->prims, &s->triShade, &s->wideNodes, &s->widePrims, &s->shadowNodes, &s->shadowTopWords };
     if ( which >= sizeof( all ) / sizeof( all[0] ) ) return Fail( PT_ERR_INVALID_ARG, "pt_read_layout: no layout %u", which );
     const DeviceBuffer& b = *all[which];
     if ( bytes ) *bytes = b.bytes;

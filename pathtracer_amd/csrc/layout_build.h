@@ -45,4 +45,24 @@ void BuildPrimRecords( hipStream_t stream, const LayoutInputs& in, float4* prims
 // The intersection records once more in the order of the wide layout, the primitive's reference index in word 3
 void GatherWidePrims( hipStream_t stream, const LayoutInputs& in, const float4* prims, const uint32_t* primOrder, float4* widePrims );
 
+// Third layout (one directional light): bounds of every node in the light's frame, then 16-byte records on a 16-bit grid.
+struct ShadowAxes
+{
+    float u[3], v[3]; // the two axes of the light's frame across the rays
+};
+struct ShadowGrid
+{
+    double origin[2], cell[2], slack[2]; // the grid the rectangles are rounded to, and what they are widened by first (in cells)
+    uint32_t depthAxis, towardsPositive; // the world axis the rays mostly travel along, and in which sense
+    uint32_t shadowTop, numRecords;      // records of the top of the tree, all records
+};
+// parent, arrivals: numNodes words of scratch each; frame: 4 floats per node {u0, u1, v0, v1}
+void BuildShadowFrames( hipStream_t stream, const LayoutInputs& in, const ShadowAxes& axes, uint32_t* parent, uint32_t* arrivals, float* frame );
+// before[i] (numNodes + 1 words) <- records that nodes with a smaller reference index take behind the top; before[numNodes] is
+// their total.  blockSums: LayoutScanBlocks( numNodes ) + 1 words of scratch
+void CountShadowRecords( hipStream_t stream, const LayoutInputs& in, const uint32_t* topSorted, const uint32_t* topRank, uint32_t topCount, uint32_t shadowTop,
+                         uint32_t* before, uint32_t* blockSums );
+void BuildShadowRecords( hipStream_t stream, const LayoutInputs& in, const float* frame, const ShadowGrid& grid, const uint32_t* topSorted, const uint32_t* topRank,
+                         uint32_t topCount, const uint32_t* before, uint4* rec, uint32_t* topWords );
+
 } // namespace ptd

@@ -277,6 +277,210 @@ __global__ __launch_bounds__( kBlock ) void WidePrimsKernel( LayoutInputs in, co
     o[3] = q[3];
 }
 
+// ---- third layout: the light-space records of a scene lit by one directional light
+
+__device__ __forceinline__ float RoundedDown( double x )
+{
+    float f = static_cast< float >( x );
+    if ( static_cast< double >( f ) > x ) f = nextafterf( f, -INFINITY );
+    return f;
+}
+__device__ __forceinline__ float RoundedUp( double x )
+{
+    float f = static_cast< float >( x );
+    if ( static_cast< double >( f ) < x ) f = nextafterf( f, INFINITY );
+    return f;
+}
+
+__device__ __forceinline__ float LoadShared( const float* p ) { return __hip_atomic_load( p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ); }
+
+__global__ __launch_bounds__( kBlock ) void ParentsKernel( LayoutInputs in, uint32_t* __restrict__ parent )
+{
+    const uint32_t x = GlobalIndex();
+    if ( x >= in.numNodes ) return;
+    if ( x == 0 ) parent[0] = kUnset;
+    const PtBvhNode n = in.nodes[x];
+    if ( n.num_shapes > 0 ) return;
+    parent[x + 1] = x;
+    parent[static_cast< uint32_t >( n.offset )] = x;
+}
+
+// Bounds of every node in the light's frame {u0, u1, v0, v1}, from the geometry below it: a leaf from its primitives, then
+// up the tree - the second child to arrive at a parent finds its sibling's bounds written and goes on, the first leaves.
+__global__ __launch_bounds__( kBlock ) void ShadowFramesKernel( LayoutInputs in, ShadowAxes axes, const uint32_t* __restrict__ parent, uint32_t* __restrict__ arrivals,
+                                                                float* __restrict__ frame )
+{
+    const uint32_t i = GlobalIndex();
+    if ( i >= in.numNodes ) return;
+    const PtBvhNode n = in.nodes[i];
+    if ( n.num_shapes == 0 ) return;
+    double lo[2] = { INFINITY, INFINITY }, hi[2] = { -INFINITY, -INFINITY };
+    for ( uint32_t k = 0; k < n.num_shapes; ++k )
+    {
+        const PtPrim prim = in.prims[static_cast< uint64_t >( n.offset ) + k];
+        if ( prim.type == PT_PRIM_TRIANGLE )
+        {
+            const PtTriangle t = in.triangles[prim.index];
+            const PtMesh m     = in.meshes[t.mesh];
+            const uint32_t idx[3] = { t.i0, t.i1, t.i2 };
+            for ( int c = 0; c < 3; ++c )
+            {
+                const float* p = VertexOf( in.vertices, m, idx[c], 3 );
+                for ( int a = 0; a < 2; ++a )
+                {
+                    const float* ax = a ? axes.v : axes.u;
+                    const double q = static_cast< double >( p[0] ) * ax[0] + static_cast< double >( p[1] ) * ax[1] + static_cast< double >( p[2] ) * ax[2];
+                    lo[a] = q < lo[a] ? q : lo[a];
+                    hi[a] = hi[a] < q ? q : hi[a];
+                }
+            }
+        }
+        else
+        {
+            const PtSphere sp = in.spheres[prim.index];
+            for ( int a = 0; a < 2; ++a )
+            {
+                const float* ax = a ? axes.v : axes.u;
+                const double q   = static_cast< double >( sp.position[0] ) * ax[0] + static_cast< double >( sp.position[1] ) * ax[1] + static_cast< double >( sp.position[2] ) * ax[2];
+                const double len = sqrt( static_cast< double >( ax[0] ) * ax[0] + static_cast< double >( ax[1] ) * ax[1] + static_cast< double >( ax[2] ) * ax[2] );
+                const double r   = fabs( static_cast< double >( sp.radius ) ) * len * ( 1.0 + 1e-6 );
+                lo[a] = q - r < lo[a] ? q - r : lo[a];
+                hi[a] = hi[a] < q + r ? q + r : hi[a];
+            }
+        }
+    }
+    float f[4] = { RoundedDown( lo[0] ), RoundedUp( hi[0] ), RoundedDown( lo[1] ), RoundedUp( hi[1] ) };
+    for ( uint32_t y = i;; )
+    {
+        float* mine = frame + 4ull * y;
+        for ( int k = 0; k < 4; ++k ) __hip_atomic_store( mine + k, f[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+        const uint32_t p = parent[y];
+        if ( p == kUnset ) break;
+        __threadfence();
+        if ( atomicAdd( arrivals + p, 1u ) == 0 ) break; // the sibling is still on its way: it will do the parent
+        __threadfence();
+        const uint32_t sibling = y == p + 1 ? static_cast< uint32_t >( in.nodes[p].offset ) : p + 1;
+        const float* other = frame + 4ull * sibling;
+        // min( first child, second child ) as the host writes it: the second argument only where it is smaller
+        const float a0 = LoadShared( other ), a1 = LoadShared( other + 1 ), a2 = LoadShared( other + 2 ), a3 = LoadShared( other + 3 );
+        const bool iAmFirst = y == p + 1;
+        const float x0 = iAmFirst ? f[0] : a0, y0 = iAmFirst ? a0 : f[0], x1 = iAmFirst ? f[1] : a1, y1 = iAmFirst ? a1 : f[1];
+        const float x2 = iAmFirst ? f[2] : a2, y2 = iAmFirst ? a2 : f[2], x3 = iAmFirst ? f[3] : a3, y3 = iAmFirst ? a3 : f[3];
+        f[0] = y0 < x0 ? y0 : x0; // std::min( x, y )
+        f[1] = x1 < y1 ? y1 : x1; // std::max( x, y )
+        f[2] = y2 < x2 ? y2 : x2;
+        f[3] = x3 < y3 ? y3 : x3;
+        y = p;
+    }
+}
+
+// Is reference node i one of the first shadowTop nodes of the top of the tree, and if so which
+__device__ __forceinline__ bool ShadowTopRank( const uint32_t* __restrict__ topSorted, const uint32_t* __restrict__ topRank, uint32_t topCount, uint32_t shadowTop, uint32_t i,
+                                               uint32_t* rank )
+{
+    const uint32_t k = LastNotAbove( topSorted, topCount, i );
+    if ( k == topCount || topSorted[k] != i || topRank[k] >= shadowTop ) return false;
+    *rank = topRank[k];
+    return true;
+}
+
+// Records a node takes in the part behind the top: none if it is in the top, else one, and one more for a leaf whose
+// successor lies in the top (the record that links back there)
+__global__ __launch_bounds__( kBlock ) void ShadowSlotsKernel( LayoutInputs in, const uint32_t* __restrict__ topSorted, const uint32_t* __restrict__ topRank, uint32_t topCount,
+                                                               uint32_t shadowTop, uint32_t* __restrict__ slots )
+{
+    const uint32_t i = GlobalIndex();
+    if ( i > in.numNodes ) return;
+    uint32_t rank, count = 0;
+    if ( i < in.numNodes && !ShadowTopRank( topSorted, topRank, topCount, shadowTop, i, &rank ) )
+    {
+        count = 1;
+        const uint32_t next = in.escape[i];
+        if ( in.nodes[i].num_shapes > 0 && next < in.numNodes && ShadowTopRank( topSorted, topRank, topCount, shadowTop, next, &rank ) ) count = 2;
+    }
+    slots[i] = count;
+}
+
+__global__ __launch_bounds__( kBlock ) void SumTilesKernel( const uint32_t* __restrict__ values, uint32_t count, uint32_t* __restrict__ blockSums )
+{
+    __shared__ uint32_t total;
+    if ( threadIdx.x == 0 ) total = 0;
+    __syncthreads();
+    const uint32_t first = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+    uint32_t mine = 0;
+    for ( uint32_t k = 0; k < kScanItems; ++k ) mine += first + k < count ? values[first + k] : 0u;
+    atomicAdd( &total, mine );
+    __syncthreads();
+    if ( threadIdx.x == 0 ) blockSums[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__( kBlock ) void PrefixTilesKernel( uint32_t* __restrict__ values, uint32_t count, const uint32_t* __restrict__ blockSums )
+{
+    // values[i] <- sum of the values before i
+    __shared__ uint32_t sums[kBlock];
+    const uint32_t first = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+    uint32_t v[kScanItems], mine = 0;
+    for ( uint32_t k = 0; k < kScanItems; ++k )
+    {
+        v[k] = first + k < count ? values[first + k] : 0u;
+        mine += v[k];
+    }
+    sums[threadIdx.x] = mine;
+    __syncthreads();
+    for ( uint32_t step = 1; step < kBlock; step <<= 1 )
+    {
+        const uint32_t add = threadIdx.x >= step ? sums[threadIdx.x - step] : 0u;
+        __syncthreads();
+        sums[threadIdx.x] += add;
+        __syncthreads();
+    }
+    uint32_t run = blockSums[blockIdx.x] + sums[threadIdx.x] - mine;
+    for ( uint32_t k = 0; k < kScanItems; ++k )
+    {
+        if ( first + k < count ) values[first + k] = run;
+        run += v[k];
+    }
+}
+
+__global__ __launch_bounds__( kBlock ) void ShadowRecordsKernel( LayoutInputs in, const float* __restrict__ frame, ShadowGrid grid, const uint32_t* __restrict__ topSorted,
+                                                                 const uint32_t* __restrict__ topRank, uint32_t topCount, const uint32_t* __restrict__ before,
+                                                                 uint4* __restrict__ rec, uint32_t* __restrict__ topWords )
+{
+    const uint32_t i = GlobalIndex();
+    if ( i >= in.numNodes ) return;
+    auto recordOf = [&]( uint32_t j ) {
+        uint32_t rank;
+        if ( j >= in.numNodes ) return grid.numRecords; // the end of the traversal
+        return ShadowTopRank( topSorted, topRank, topCount, grid.shadowTop, j, &rank ) ? rank : grid.shadowTop + before[j];
+    };
+    const PtBvhNode n = in.nodes[i];
+    uint32_t q[2];
+    const float* f = frame + 4ull * i;
+    for ( int a = 0; a < 2; ++a )
+    {
+        const double lo = f[2 * a], hi = f[2 * a + 1];
+        // std::min( 65534.0, std::max( 1.0, . ) ) and std::min( 65534.0, std::max( qlo, . ) ), comparisons in their order
+        double qlo = floor( ( lo - grid.origin[a] ) / grid.cell[a] - grid.slack[a] );
+        qlo = 1.0 < qlo ? qlo : 1.0;
+        qlo = qlo < 65534.0 ? qlo : 65534.0;
+        double qhi = floor( ( hi - grid.origin[a] ) / grid.cell[a] + grid.slack[a] );
+        qhi = qlo < qhi ? qhi : qlo;
+        qhi = qhi < 65534.0 ? qhi : 65534.0;
+        q[a] = static_cast< uint32_t >( qlo ) | static_cast< uint32_t >( qhi - qlo ) << 16;
+    }
+    const float wmax = grid.towardsPositive ? n.aabb_max[grid.depthAxis] : -n.aabb_min[grid.depthAxis];
+    const bool leaf     = n.num_shapes > 0;
+    const uint32_t next = in.escape[i];
+    const uint32_t link = recordOf( next );
+    const uint32_t word = leaf ? kLeafFlag | static_cast< uint32_t >( n.offset ) | ( static_cast< uint32_t >( n.num_shapes - 1 ) << 28 ) : link;
+    const uint32_t at   = recordOf( i );
+    rec[at] = make_uint4( q[0], q[1], __float_as_uint( wmax ), word );
+    if ( at < grid.shadowTop )
+        topWords[at] = leaf ? link : recordOf( i + 1 );
+    else if ( leaf && next < in.numNodes && link < grid.shadowTop )
+        rec[at + 1] = make_uint4( 1u, 1u, __float_as_uint( -INFINITY ), link ); // no ray enters it; it links back into the top
+}
+
 } // namespace
 
 void BuildReferenceNodes( hipStream_t stream, const LayoutInputs& in, const uint32_t* topSorted, const uint32_t* topRank, uint32_t topCount, float4* out )
@@ -312,6 +516,31 @@ void GatherWidePrims( hipStream_t stream, const LayoutInputs& in, const float4* 
 {
     if ( in.numPrims == 0 ) return;
     hipLaunchKernelGGL( WidePrimsKernel, dim3( BlocksFor( in.numPrims ) ), dim3( kBlock ), 0, stream, in, prims, primOrder, widePrims );
+}
+
+void BuildShadowFrames( hipStream_t stream, const LayoutInputs& in, const ShadowAxes& axes, uint32_t* parent, uint32_t* arrivals, float* frame )
+{
+    if ( in.numNodes == 0 ) return;
+    hipLaunchKernelGGL( ParentsKernel, dim3( BlocksFor( in.numNodes ) ), dim3( kBlock ), 0, stream, in, parent );
+    (void)hipMemsetAsync( arrivals, 0, 4ull * in.numNodes, stream );
+    hipLaunchKernelGGL( ShadowFramesKernel, dim3( BlocksFor( in.numNodes ) ), dim3( kBlock ), 0, stream, in, axes, parent, arrivals, frame );
+}
+
+void CountShadowRecords( hipStream_t stream, const LayoutInputs& in, const uint32_t* topSorted, const uint32_t* topRank, uint32_t topCount, uint32_t shadowTop,
+                         uint32_t* before, uint32_t* blockSums )
+{
+    const uint32_t count = in.numNodes + 1, tiles = count / kScanTile + 1u;
+    hipLaunchKernelGGL( ShadowSlotsKernel, dim3( BlocksFor( count ) ), dim3( kBlock ), 0, stream, in, topSorted, topRank, topCount, shadowTop, before );
+    hipLaunchKernelGGL( SumTilesKernel, dim3( tiles ), dim3( kBlock ), 0, stream, before, count, blockSums );
+    hipLaunchKernelGGL( ScanBlockSumsKernel, dim3( 1 ), dim3( 1 ), 0, stream, blockSums, tiles );
+    hipLaunchKernelGGL( PrefixTilesKernel, dim3( tiles ), dim3( kBlock ), 0, stream, before, count, blockSums );
+}
+
+void BuildShadowRecords( hipStream_t stream, const LayoutInputs& in, const float* frame, const ShadowGrid& grid, const uint32_t* topSorted, const uint32_t* topRank,
+                         uint32_t topCount, const uint32_t* before, uint4* rec, uint32_t* topWords )
+{
+    if ( in.numNodes == 0 ) return;
+    hipLaunchKernelGGL( ShadowRecordsKernel, dim3( BlocksFor( in.numNodes ) ), dim3( kBlock ), 0, stream, in, frame, grid, topSorted, topRank, topCount, before, rec, topWords );
 }
 
 } // namespace ptd

@@ -1,7 +1,7 @@
 """The record arrays that pt_upload_scene's kernels write from the scene description are, byte for byte, the ones its
 host loops write (PT_SCENE_HOST_LAYOUTS): reference-order nodes, front-to-back nodes with their octant links, the
-intersection and attribute records of the primitives, and the primitive copy of the wide layout.  The wide nodes and the
-light-space records are built on the host either way and must not differ either."""
+intersection and attribute records of the primitives, the wide nodes and their primitive copy, and the light-space
+records of a scene with one directional light."""
 import numpy as np
 import pytest
 
@@ -11,7 +11,8 @@ pytestmark = pytest.mark.gpu
 
 LAYOUTS = {"reference nodes": abi.PT_LAYOUT_REFERENCE_NODES, "front-to-back nodes": abi.PT_LAYOUT_ORDERED_NODES,
            "intersection records": abi.PT_LAYOUT_PRIMS, "attribute records": abi.PT_LAYOUT_ATTRIBUTES,
-           "wide nodes": abi.PT_LAYOUT_WIDE_NODES, "wide primitives": abi.PT_LAYOUT_WIDE_PRIMS, "light-space nodes": abi.PT_LAYOUT_SHADOW_NODES}
+           "wide nodes": abi.PT_LAYOUT_WIDE_NODES, "wide primitives": abi.PT_LAYOUT_WIDE_PRIMS, "light-space nodes": abi.PT_LAYOUT_SHADOW_NODES,
+           "light-space top words": abi.PT_LAYOUT_SHADOW_TOP}
 
 
 def compare(make_desc, what, expect=LAYOUTS):
@@ -66,6 +67,26 @@ def test_small_tops(top_nodes, scenes):
         desc.top_nodes = top_nodes
         return desc
     compare(make, f"mixed, top of {top_nodes}")
+
+
+@pytest.mark.parametrize("name,max_shapes", [("cornell", 1), ("mixed", 1), ("mixed", 8)])
+def test_one_directional_light(name, max_shapes, scenes):
+    """The light-space records, for lights along an axis (exact projections) and oblique ones; `mixed` has spheres, whose
+    extent in the light's frame takes a double-precision square root"""
+    from test_gpu_parallel_shadows import DIRECTIONS, one_directional_light
+    from test_gpu_parity import collapse_small_subtrees
+    for label, direction in DIRECTIONS.items():
+        s = one_directional_light(scenes[name], direction)
+        if max_shapes > 1:
+            s = collapse_small_subtrees(s, max_shapes)
+        for top_nodes in (0, 3, 200):
+            def make(flags):
+                desc = s.to_desc(flags=flags)
+                if top_nodes:
+                    desc.top_nodes = top_nodes
+                return desc
+            sizes = compare(make, f"{name}, leaves of up to {max_shapes}, light {label}, top of {top_nodes or 'default'}")
+            assert sizes["light-space nodes"] > 0 and sizes["light-space top words"] > 0
 
 
 def with_flags(hs, flags):
