@@ -261,15 +261,18 @@ def main():
             meta = summary.get("_meta", {})
             if not default_workload:
                 why_not = "the committed counter summaries are of the default workload"
-            elif meta.get("kernel_sources") != kernel_source_hash():
+                break
+            if meta.get("traversal") != mode:   # the summary of another mode: look on
+                if profile is None and why_not.startswith("no counter"):
+                    why_not = f"no counter summary of traversal mode {mode} under profiles/"
+                continue
+            if meta.get("kernel_sources") != kernel_source_hash():
                 why_not = f"{os.path.relpath(path, ROOT)} was collected with other kernel sources"
-            elif meta.get("traversal") != mode:
-                why_not = f"{os.path.relpath(path, ROOT)} was collected in another traversal mode"
-            else:
-                name = next((k for k in sorted(summary) if instance(k)), None)
-                if name and "per_dispatch" in summary[name]:
-                    profile, profile_name, kernel = summary[name], os.path.relpath(path, ROOT), name
-            break
+                continue
+            name = next((k for k in sorted(summary) if instance(k)), None)
+            if name and "per_dispatch" in summary[name]:
+                profile, profile_name, kernel = summary[name], os.path.relpath(path, ROOT), name
+                break
         hbm = {"peak": HBM_PEAK_GBS, "unit": "GB/s",
                "algorithmic": round(algorithmic_gbs, 1), "algorithmic_frac": round(algorithmic_gbs / HBM_PEAK_GBS, 4),
                "compulsory": round(compulsory_gbs, 1), "compulsory_frac": round(compulsory_gbs / HBM_PEAK_GBS, 4),
