@@ -112,6 +112,29 @@ def test_soup_2m():
         compare(lambda flags: with_flags(hs, flags), "soup 2M")
 
 
+def lit_from(hs, flags, direction):
+    """The generated scene with one directional light in place of its own"""
+    desc = with_flags(hs, flags)
+    light = np.zeros(1, abi.LIGHT_DTYPE)
+    light["type"], light["n_samples"], light["prim"] = abi.PT_LIGHT_DIRECTIONAL, 1, -1
+    light["Lemit"], light["direction"] = (5, 5, 5), np.asarray(direction, np.float32)
+    desc.lights, desc.num_lights = light.ctypes.data, 1
+    desc._light = light
+    return desc
+
+
+@pytest.mark.parametrize("direction", [(0, -1, 0), (0.3, -0.8, 0.5)])
+def test_large_trees_with_one_directional_light(direction):
+    """4 M and 1.7 M nodes: the bounds in the light's frame climb the tree over many levels, and the record indices come
+    from a prefix sum over hundreds of blocks"""
+    with host.HostScene.soup(seed=5, triangles=2_000_000, edge=0.01, skybox_size=64) as hs:
+        sizes = compare(lambda flags: lit_from(hs, flags, direction), f"soup 2M, light {direction}")
+        assert sizes["light-space nodes"] >= 16 * (4_000_000 - 1)
+    with host.HostScene.knot(seed=2, triangles=871414) as hs:
+        sizes = compare(lambda flags: lit_from(hs, flags, direction), f"knot, light {direction}")
+        assert sizes["light-space nodes"] > 0
+
+
 def test_films_agree(scenes):
     """and a render over each set of records gives the same film"""
     s = scenes["mixed"].with_image(64, 64)
