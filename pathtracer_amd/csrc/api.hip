@@ -688,7 +688,8 @@ int Upload( PtScene* s, const PtSceneDesc* d, const std::vector< uint32_t >& esc
         for ( int a = 1; a < 3; ++a )
             if ( std::fabs( w[a] ) > std::fabs( w[depthAxis] ) ) depthAxis = a;
         // a record's word keeps bit 31 for the leaf flag, which leaves three bits for a leaf's shape count
-        for ( uint32_t i = 0; i < N && build; ++i ) build = d->nodes[i].num_shapes <= 8;
+        // (the kernels that make the bounds look for such a leaf themselves)
+        for ( uint32_t i = 0; i < N && build && hostLayouts; ++i ) build = d->nodes[i].num_shapes <= 8;
         if ( build && zeros == 2 )
         {
             // along an axis: the other two axes as they are, and the projections are exact
@@ -781,11 +782,21 @@ int Upload( PtScene* s, const PtSceneDesc* d, const std::vector< uint32_t >& esc
                 axes.u[a] = fu[a];
                 axes.v[a] = fv[a];
             }
+            DeviceBuffer dVerdict;
             HIP_TRY( dFrame.Allocate( 16ull * N ) );
             HIP_TRY( dParent.Allocate( 4ull * N ) );
             HIP_TRY( dArrivals.Allocate( 4ull * N ) );
-            BuildShadowFrames( nullptr, in, axes, dParent.As< uint32_t >(), dArrivals.As< uint32_t >(), dFrame.As< float >() );
-            HIP_TRY( hipGetLastError() );
+            HIP_TRY( dVerdict.Allocate( 4 ) );
+            // the fast climb first; should its check ever fail, once more with full fences (PTAMD_SHADOW_FULL_FENCES: at once)
+            uint32_t verdict = kShadowFramesWrong;
+            for ( int attempt = std::getenv( "PTAMD_SHADOW_FULL_FENCES" ) ? 1 : 0; attempt < 2 && ( verdict & kShadowFramesWrong ); ++attempt )
+            {
+                BuildShadowFrames( nullptr, in, axes, attempt == 1, dParent.As< uint32_t >(), dArrivals.As< uint32_t >(), dFrame.As< float >(), dVerdict.As< uint32_t >() );
+                HIP_TRY( hipGetLastError() );
+                HIP_TRY( hipMemcpy( &verdict, dVerdict.ptr, 4, hipMemcpyDeviceToHost ) );
+            }
+            if ( verdict & kShadowFramesWrong ) return Fail( PT_ERR_DEVICE, "pt_upload_scene: the bounds in the light's frame failed their check" );
+            if ( verdict & kShadowLeafTooLarge ) build = false;
             HIP_TRY( hipMemcpy( rootFrame, dFrame.ptr, 16, hipMemcpyDeviceToHost ) );
         }
         else if ( build )

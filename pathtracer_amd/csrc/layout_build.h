@@ -56,8 +56,12 @@ struct ShadowGrid
     uint32_t depthAxis, towardsPositive; // the world axis the rays mostly travel along, and in which sense
     uint32_t shadowTop, numRecords;      // records of the top of the tree, all records
 };
-// parent, arrivals: numNodes words of scratch each; frame: 4 floats per node {u0, u1, v0, v1}
-void BuildShadowFrames( hipStream_t stream, const LayoutInputs& in, const ShadowAxes& axes, uint32_t* parent, uint32_t* arrivals, float* frame );
+// parent, arrivals: numNodes words of scratch each; frame: 4 floats per node {u0, u1, v0, v1}, 16-byte aligned; verdict: one
+// word, 0 afterwards or a sum of the bits below.  fullFences: agent-scope fences in the climb (slow; see ShadowFramesKernel)
+constexpr uint32_t kShadowLeafTooLarge = 1u; // a leaf holds more than 8 shapes: the records have no room for that count
+constexpr uint32_t kShadowFramesWrong  = 2u; // an inner node's bounds are not its children's joined: the bounds must not be used
+void BuildShadowFrames( hipStream_t stream, const LayoutInputs& in, const ShadowAxes& axes, bool fullFences, uint32_t* parent, uint32_t* arrivals, float* frame,
+                        uint32_t* verdict );
 // before[i] (numNodes + 1 words) <- records that nodes with a smaller reference index take behind the top; before[numNodes] is
 // their total.  blockSums: LayoutScanBlocks( numNodes ) + 1 words of scratch
 void CountShadowRecords( hipStream_t stream, const LayoutInputs& in, const uint32_t* topSorted, const uint32_t* topRank, uint32_t topCount, uint32_t shadowTop,

@@ -135,6 +135,15 @@ def test_large_trees_with_one_directional_light(direction):
         assert sizes["light-space nodes"] > 0
 
 
+def test_bounds_with_full_fences(monkeypatch):
+    """The climb that makes the bounds in the light's frame with agent-scope fences around its arrival counter - what an
+    upload falls back to should the fast climb ever fail its check - writes the same bytes"""
+    monkeypatch.setenv("PTAMD_SHADOW_FULL_FENCES", "1")
+    with host.HostScene.atrium(seed=4, triangles=60000, texture_size=64) as hs:
+        sizes = compare(lambda flags: with_flags(hs, flags), "atrium 60 k, fenced climb")
+        assert sizes["light-space nodes"] > 0
+
+
 def test_films_agree(scenes):
     """and a render over each set of records gives the same film"""
     s = scenes["mixed"].with_image(64, 64)
