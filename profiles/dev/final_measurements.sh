@@ -6,6 +6,8 @@ TAG=${1:-r03}
 OUT=gpurun_out
 for m in wide ordered reference; do
   timeout -k 10 420 profiles/collect_pmc.sh ${TAG}_$m $m > /dev/null 2>&1 || { echo "collect $m failed"; exit 1; }
+  # the bench lines below take their counters from the summary of these very sources
+  cp $OUT/${TAG}_$m/pmc_summary.json profiles/${TAG}_${m}_pmc_summary.json
 done
 timeout -k 10 400 python3 bench.py > $OUT/${TAG}_bench_wide.json 2> $OUT/${TAG}_bench_wide.err || { echo "bench failed"; exit 1; }
 for m in ordered reference; do
