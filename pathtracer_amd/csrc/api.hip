@@ -253,6 +253,8 @@ struct PtScene
     int wideShadowBlocks = 512, wideShadowThreads = 768;       // the wide any-hit kernel
     uint32_t topNodes = 0;                          // nodes at the front of the device array in breadth-first order
     bool directSum = false;                         // one light with one sample: ConnectKernel adds the direct light, no ResolveKernel
+    bool oneDirectionalLight = false;               // that light is directional; towardsLight = -direction (wi of src/lights.cpp:30)
+    float towardsLight[3] = { 0, 0, 0 };
 
     // scene
     DeviceBuffer wideNodes, widePrims, wideSpill;
@@ -1176,6 +1178,8 @@ int Upload( PtScene* s, const PtSceneDesc* d, const std::vector< uint32_t >& esc
     v.numLights     = static_cast< uint32_t >( d->num_lights );
     v.shadowSlots   = slots;
     s->directSum    = d->num_lights == 1 && d->lights[0].n_samples == 1 && !( d->flags & PT_SCENE_NO_DIRECT_SUM );
+    s->oneDirectionalLight = d->num_lights == 1 && d->lights[0].type == PT_LIGHT_DIRECTIONAL;
+    for ( int a = 0; a < 3 && s->oneDirectionalLight; ++a ) s->towardsLight[a] = -d->lights[0].direction[a];
     v.drawsPerBounce = static_cast< int32_t >( 2 * areaSamples + 2 );
     v.skyboxWidth   = d->skybox_width;
     v.skyboxHeight  = d->skybox_height;
@@ -1490,6 +1494,8 @@ try
         HIP_TRY( hipMemsetAsync( s->cursors.ptr, 0, s->cursors.bytes, stream ) );
 
         std::memcpy( pb.origin0, cam.position, sizeof( pb.origin0 ) );
+        pb.constantShadowDir = ( wideShadows && s->directSum && s->oneDirectionalLight ) ? 1u : 0u;
+        std::memcpy( pb.shadowDir, s->towardsLight, sizeof( pb.shadowDir ) );
         int span = timer.Begin( PT_K_RAYGEN );
         LaunchRaygen( cfg, cam, rng, pb, s->width, s->height, static_cast< uint32_t >( begin ), numPaths );
         timer.End( span );

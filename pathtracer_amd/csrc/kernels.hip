@@ -1681,7 +1681,9 @@ __global__ __launch_bounds__( kConnectBlock ) PT_CONNECT_OCCUPANCY void ConnectK
 #endif
 constexpr uint32_t kWideShadowDeferred = PT_WIDE_SHADOW_DEFERRED;
 
-template < bool kDirectSum >
+// kOneDirection (pb.constantShadowDir): every ray has the direction pb.shadowDir and no end - the direction, its
+// reciprocals and its signs are the same in every lane, and a refill reads the ray's origin only.
+template < bool kDirectSum, bool kOneDirection = false >
 __global__ __launch_bounds__( kWideBlock ) __attribute__( ( amdgpu_waves_per_eu( PT_WIDE_WAVES, PT_WIDE_WAVES ) ) )
 void ConnectWideKernel( SceneView sv, PathBuffers pb, int bounce, uint2* spill, uint64_t* stats )
 {
@@ -1699,6 +1701,14 @@ void ConnectWideKernel( SceneView sv, PathBuffers pb, int bounce, uint2* spill, 
     f3 o = F3( 0.0f, 0.0f, 0.0f ), d = o, inv = o, invW = o;
     float tMax = 0.0f;
     bool nx = false, ny = false, nz = false, occluded = false;
+    if constexpr ( kOneDirection )
+    {
+        d    = F3( pb.shadowDir[0], pb.shadowDir[1], pb.shadowDir[2] );
+        tMax = FLT_MAX;                                       // src/lights.cpp:31
+        inv  = F3( 1.0f / d.x, 1.0f / d.y, 1.0f / d.z ); // bvh.cpp:275-276
+        nx = inv.x < 0; ny = inv.y < 0; nz = inv.z < 0;
+        invW = WideInv( inv );
+    }
     uint32_t sp = 0;
     uint32_t waveRays = 0, waveNodes = 0, waveTris = 0, waveSpheres = 0, waveSteps = 0; // whole-wave totals, wave-uniform
 
@@ -1739,16 +1749,21 @@ void ConnectWideKernel( SceneView sv, PathBuffers pb, int bounce, uint2* spill, 
                 {
                     rec = pb.shadowRays[stream.base + stream.taken + rank];
                     uint32_t entry = pb.shadowSlots == 1 ? rec : rec % entries; // record index = slot * entries + entry
-                    asm volatile( "" : "+v"( entry ) );                              // the index first, then both loads in one go
-                    float4 dir = pb.shDir[rec];
-                    float4 org = pb.shadowO[entry];
-                    asm volatile( "" : "+v"( dir.x ), "+v"( org.x ) ); // both loads in flight before either is waited for
-                    o    = F3( org );
-                    d    = F3( dir );
-                    tMax = dir.w;
-                    inv  = F3( 1.0f / d.x, 1.0f / d.y, 1.0f / d.z ); // bvh.cpp:275-276
-                    nx = inv.x < 0; ny = inv.y < 0; nz = inv.z < 0;
-                    invW     = WideInv( inv );
+                    if constexpr ( kOneDirection )
+                        o = F3( pb.shadowO[entry] );
+                    else
+                    {
+                        asm volatile( "" : "+v"( entry ) );                              // the index first, then both loads in one go
+                        float4 dir = pb.shDir[rec];
+                        float4 org = pb.shadowO[entry];
+                        asm volatile( "" : "+v"( dir.x ), "+v"( org.x ) ); // both loads in flight before either is waited for
+                        o    = F3( org );
+                        d    = F3( dir );
+                        tMax = dir.w;
+                        inv  = F3( 1.0f / d.x, 1.0f / d.y, 1.0f / d.z ); // bvh.cpp:275-276
+                        nx = inv.x < 0; ny = inv.y < 0; nz = inv.z < 0;
+                        invW = WideInv( inv );
+                    }
                     occluded = false;
                     sp       = 1u;
                     myLds[0] = make_uint2( 0u, 0x0101u ); // the root as the one child of a node above it
@@ -2198,7 +2213,7 @@ __global__ __launch_bounds__( kBlock ) void ShadeKernel( SceneView sv, RngParams
                     else
                         est = ( ( sf.F * Li ) * AbsDot( sf.normal, wi ) ) / pdf; // path_tracer.cpp:87
                     if ( IsZero( est ) ) skip = true;
-                    pb.shDir[rec] = F4( wi, skip ? -1.0f : tMax );
+                    if ( !pb.constantShadowDir ) pb.shDir[rec] = F4( wi, skip ? -1.0f : tMax ); // else: nobody reads it
                     if ( !skip )
                     {
                         if ( pb.directSum )
@@ -2523,7 +2538,9 @@ void LaunchConnect( const LaunchCfg& cfg, const SceneView& sv, const PathBuffers
 {
     if ( cfg.wideShadows )
     {
-        if ( pb.directSum )
+        if ( pb.directSum && pb.constantShadowDir )
+            hipLaunchKernelGGL( ( ConnectWideKernel< true, true > ), dim3( cfg.wideShadowBlocks ), dim3( kWideBlock ), 0, cfg.stream, sv, pb, bounce, cfg.wideSpill, stats );
+        else if ( pb.directSum )
             hipLaunchKernelGGL( ( ConnectWideKernel< true > ), dim3( cfg.wideShadowBlocks ), dim3( kWideBlock ), 0, cfg.stream, sv, pb, bounce, cfg.wideSpill, stats );
         else
             hipLaunchKernelGGL( ( ConnectWideKernel< false > ), dim3( cfg.wideShadowBlocks ), dim3( kWideBlock ), 0, cfg.stream, sv, pb, bounce, cfg.wideSpill, stats );

@@ -143,6 +143,10 @@ struct PathBuffers
     uint32_t shadowSlots;   // shadow records per path, at least 1
     uint32_t directSum;     // 1: one light with one sample - ConnectKernel adds the direct light itself, no ResolveKernel
     float origin0[3];       // where every ray of bounce 0 starts (the camera): not stored per path, like the throughput 1 they start with
+    // 1: every shadow ray of this render has the direction shadowDir and no end (one directional light, one sample, traced by
+    // ConnectWideKernel): ShadeKernel does not write shDir and the any-hit kernel does not read it
+    uint32_t constantShadowDir;
+    float shadowDir[3];
 };
 
 // Paths per unit of work; every queue has one segment of this many entries (times shadowSlots for shadowRays) per unit
