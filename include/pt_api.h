@@ -382,7 +382,8 @@ enum
     PT_LAYOUT_WIDE_NODES      = 4, /* 80-byte nodes of up to eight children                         */
     PT_LAYOUT_WIDE_PRIMS      = 5, /* intersection records in the wide layout's order               */
     PT_LAYOUT_SHADOW_NODES    = 6, /* 16-byte light-space records (one directional light)           */
-    PT_LAYOUT_SHADOW_TOP      = 7  /* the second word of the first of those records (kept in LDS)   */
+    PT_LAYOUT_SHADOW_TOP      = 7, /* the second word of the first of those records (kept in LDS)   */
+    PT_LAYOUT_LIGHT_WIDE_NODES = 8 /* 64-byte records: the wide nodes in the directional light's frame */
 };
 int pt_read_layout( PtScene* scene, uint32_t which, void* dst, uint64_t capacity, uint64_t* bytes );
 

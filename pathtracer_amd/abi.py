@@ -21,7 +21,7 @@ PT_SCENE_NO_DIRECT_SUM, PT_SCENE_TOP_BREADTH_FIRST, PT_SCENE_NO_ORDERED_LAYOUT, 
 PT_SCENE_NO_WIDE_LAYOUT = 16
 PT_SCENE_HOST_LAYOUTS = 32
 (PT_LAYOUT_REFERENCE_NODES, PT_LAYOUT_ORDERED_NODES, PT_LAYOUT_PRIMS, PT_LAYOUT_ATTRIBUTES, PT_LAYOUT_WIDE_NODES, PT_LAYOUT_WIDE_PRIMS,
- PT_LAYOUT_SHADOW_NODES, PT_LAYOUT_SHADOW_TOP) = range(8)
+ PT_LAYOUT_SHADOW_NODES, PT_LAYOUT_SHADOW_TOP, PT_LAYOUT_LIGHT_WIDE_NODES) = range(9)
 PT_MERGE_STAGE_ALWAYS = 1
 PT_K_RAYGEN, PT_K_EXTEND, PT_K_SHADE, PT_K_CONNECT, PT_K_FILM, PT_K_TONEMAP, PT_K_RESOLVE, PT_K_COUNT = range(8)
 KERNEL_NAMES = ("raygen", "extend", "shade", "connect", "film", "tonemap", "resolve")

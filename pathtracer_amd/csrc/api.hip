@@ -257,7 +257,7 @@ struct PtScene
     float towardsLight[3] = { 0, 0, 0 };
 
     // scene
-    DeviceBuffer wideNodes, widePrims, wideSpill;
+    DeviceBuffer wideNodes, widePrims, wideSpill, lightWideNodes;
     DeviceBuffer nodes, orderedNodes, shadowNodes, shadowTopWords, prims, triShade, spheres, materials, textures, texels, lights, skybox;
     SceneView view{};
     PtCamera camera{};
@@ -678,6 +678,9 @@ int Upload( PtScene* s, const PtSceneDesc* d, const std::vector< uint32_t >& esc
     // leaf of the lower part whose successor lies in the top part gets a record of its own behind it that no ray enters
     // (wmax = -inf) and that links there.  Top records: inner {link, first child}, leaf {flag | leaf word, link}.
     uint32_t numShadow = 0, shadowTop = 0;
+    ShadowAxes lightAxes{};  // kept for the wide tree in the light's frame, which is made once the wide layout is there
+    ShadowGrid lightGrid{};
+    bool lightGridMade = false;
     if ( !( d->flags & PT_SCENE_NO_PARALLEL_SHADOWS ) && d->num_lights == 1 && d->lights[0].type == PT_LIGHT_DIRECTIONAL )
     {
         const double w[3] = { -static_cast< double >( d->lights[0].direction[0] ), -static_cast< double >( d->lights[0].direction[1] ),
@@ -855,6 +858,13 @@ int Upload( PtScene* s, const PtSceneDesc* d, const std::vector< uint32_t >& esc
             grid.towardsPositive = w[depthAxis] > 0;
             grid.shadowTop       = shadowTop;
             grid.numRecords      = numShadow;
+            lightGrid            = grid;
+            lightGridMade        = true;
+            for ( int a = 0; a < 3; ++a )
+            {
+                lightAxes.u[a] = fu[a];
+                lightAxes.v[a] = fv[a];
+            }
             HIP_TRY( s->shadowNodes.Allocate( 16ull * numShadow ) );
             HIP_TRY( s->shadowTopWords.Allocate( 4ull * shadowTop ) );
             BuildShadowRecords( nullptr, in, dFrame.As< float >(), grid, dTopSorted.As< uint32_t >(), dTopRank.As< uint32_t >(), static_cast< uint32_t >( bfs.size() ),
@@ -1071,6 +1081,28 @@ int Upload( PtScene* s, const PtSceneDesc* d, const std::vector< uint32_t >& esc
     prims.reset();
     phase( "wide nodes and primitives" );
 
+    // The wide nodes once more in the frame of the one directional light (ConnectLightWideKernel): made by kernels from the
+    // wide layout and the grid of the third layout.  A scene uploaded with PT_SCENE_HOST_LAYOUTS has none (its shadow rays
+    // take ConnectWideKernel), nor has one whose bounds fail their check.
+    if ( lightGridMade && numWide != 0 && s->widePrims.ptr )
+    {
+        DeviceBuffer primRect, primFar, parent, arrivals, nodeBounds, verdictWord;
+        HIP_TRY( primRect.Allocate( 8ull * P ) );
+        HIP_TRY( primFar.Allocate( 4ull * P ) );
+        HIP_TRY( parent.Allocate( 4ull * numWide ) );
+        HIP_TRY( arrivals.Allocate( 4ull * numWide ) );
+        HIP_TRY( nodeBounds.Allocate( 16ull * numWide ) );
+        HIP_TRY( verdictWord.Allocate( 4 ) );
+        HIP_TRY( s->lightWideNodes.Allocate( 64ull * numWide ) );
+        BuildLightWideNodes( nullptr, in, lightAxes, lightGrid, s->wideNodes.ptr, numWide, s->widePrims.As< float4 >(), primRect.As< uint2 >(), primFar.As< float >(),
+                             parent.As< uint32_t >(), arrivals.As< uint32_t >(), nodeBounds.As< uint32_t >(), verdictWord.As< uint32_t >(), s->lightWideNodes.As< uint4 >() );
+        HIP_TRY( hipGetLastError() );
+        uint32_t verdict = 0;
+        HIP_TRY( hipMemcpy( &verdict, verdictWord.ptr, 4, hipMemcpyDeviceToHost ) );
+        if ( verdict != 0 ) s->lightWideNodes.Release();
+        phase( "wide nodes in the light's frame" );
+    }
+
     std::vector< float > spheres( 24ull * d->num_spheres, 0.0f );
     for ( uint64_t i = 0; i < d->num_spheres; ++i )
     {
@@ -1162,6 +1194,7 @@ int Upload( PtScene* s, const PtSceneDesc* d, const std::vector< uint32_t >& esc
     v.wideNodes     = s->wideNodes.As< float4 >();
     v.widePrims     = s->widePrims.As< float4 >();
     v.numWideNodes  = numWide;
+    v.lightWideNodes = s->lightWideNodes.As< float4 >();
     v.wideDepth     = wideDepth;
     v.prims         = s->prims.As< float4 >();
     v.triShade      = s->triShade.As< float4 >();
@@ -1602,7 +1635,7 @@ int pt_read_layout( PtScene* s, uint32_t which, void* dst, uint64_t capacity, ui
 try
 {
     if ( !s ) return Fail( PT_ERR_INVALID_ARG, "pt_read_layout: null scene" );
-    const DeviceBuffer* all[] = { &s->nodes, &s->orderedNodes, &s->prims, &s->triShade, &s->wideNodes, &s->widePrims, &s->shadowNodes, &s->shadowTopWords };
+    const DeviceBuffer* all[] = { &s->nodes, &s->orderedNodes, &s->prims, &s->triShade, &s->wideNodes, &s->widePrims, &s->shadowNodes, &s->shadowTopWords, &s->lightWideNodes };
     if ( which >= sizeof( all ) / sizeof( all[0] ) ) return Fail( PT_ERR_INVALID_ARG, "pt_read_layout: no layout %u", which );
     const DeviceBuffer& b = *all[which];
     if ( bytes ) *bytes = b.bytes;

@@ -1847,6 +1847,212 @@ void ConnectWideKernel( SceneView sv, PathBuffers pb, int bounce, uint2* spill, 
     FlushWaveCounter( stats, ST_STEPS_SHADOW, waveSteps );
 }
 
+// ---- the wide tree in the light's frame ------------------------------------------------------------------------
+//
+// Shadow rays of one directional light over the nodes of the wide layout (same children, same indices), each child kept
+// as ConnectParallelKernel keeps a node of the binary tree: the rectangle around its geometry on the light's grid, and
+// how far it reaches along the rays' main axis - here in bytes, relative to the node (layout_build.hip,
+// LightWideNodesKernel).  A node visit is four 16-byte loads and, per child, four integer compares and one more for the
+// reach, where the box test of ConnectWideKernel converts six bytes and computes three packed FMAs, a max3 and a min3.
+// Outer bounds again: what is found counts once the reference's own test of the primitive's leaf box has passed.
+// The rectangle: a ray's cell c lies in [first, last] (cells) if and only if ( c - origin ) >> shift lies in
+// [( first - origin ) >> shift, ( last - origin ) >> shift] or between values that map to the same bytes - the shift is
+// monotone, so nothing inside is lost; a cell below the origin wraps to a large number and fails the upper compare.
+// The reach: a child whose far plane lies at `far` can only hold what the ray meets if far > pw.  The record has
+// byte = ceil( ( far - d0 ) / step ), the ray computes t = fl( pw - d0 ) / step (step is a power of two); for |t| < 2^23
+// the rounding of the difference moves t by less than 1 / 2, so far > pw implies byte >= floor( t ); beyond 2^23 the
+// sign of t decides, rightly.  The child passes if byte >= clamp( floor( t ), 0, 256 ).
+__device__ __forceinline__ uint32_t ByteOf( uint32_t w, int k ) { return ( w >> ( 8 * k ) ) & 0xFFu; }
+
+// scheduling of ConnectLightWideKernel, as PT_WIDE_SHADOW_* for ConnectWideKernel
+#ifndef PT_LIGHT_WIDE_REFILL_LANES
+#define PT_LIGHT_WIDE_REFILL_LANES 24
+#endif
+#ifndef PT_LIGHT_WIDE_LEAF_LANES
+#define PT_LIGHT_WIDE_LEAF_LANES 20
+#endif
+#ifndef PT_LIGHT_WIDE_KEEP_LANES
+#define PT_LIGHT_WIDE_KEEP_LANES 12
+#endif
+#ifndef PT_LIGHT_WIDE_BURST
+#define PT_LIGHT_WIDE_BURST 2
+#endif
+#ifndef PT_LIGHT_WIDE_DEFERRED
+#define PT_LIGHT_WIDE_DEFERRED 2
+#endif
+constexpr uint32_t kLightWideDeferred = PT_LIGHT_WIDE_DEFERRED;
+
+__device__ __forceinline__ WideGroup LightWideVisit( BufferDesc nodes, uint32_t node, uint32_t cellU, uint32_t cellV, float pw )
+{
+    const uint32_t at = 64u * node;
+    const float4 n0 = Load16( nodes, at ), n1 = Load16( nodes, at + 16u ), n2 = Load16( nodes, at + 32u ), n3 = Load16( nodes, at + 48u );
+    const uint32_t w0 = __float_as_uint( n0.x ), w1 = __float_as_uint( n0.y );
+    const uint32_t lu = ( cellU - ( w0 & 0xFFFFu ) ) >> ( w1 & 0xFFu ), lv = ( cellV - ( w0 >> 16 ) ) >> ( ( w1 >> 8 ) & 0xFFu );
+    const float t = floorf( ( pw - n1.x ) * n1.y );
+    const uint32_t reach = static_cast< uint32_t >( __builtin_amdgcn_fmed3f( t, 0.0f, 256.0f ) ); // a NaN (no finite origin) passes as 0
+    const uint32_t far[2] = { __float_as_uint( n1.z ), __float_as_uint( n1.w ) }, u0[2] = { __float_as_uint( n2.x ), __float_as_uint( n2.y ) },
+                   u1[2] = { __float_as_uint( n2.z ), __float_as_uint( n2.w ) }, v0[2] = { __float_as_uint( n3.x ), __float_as_uint( n3.y ) },
+                   v1[2] = { __float_as_uint( n3.z ), __float_as_uint( n3.w ) };
+    uint32_t hits = 0;
+#pragma unroll
+    for ( int s = 0; s < 8; ++s )
+    {
+        const int w = s >> 2, k = s & 3;
+        const bool in = ( ByteOf( u0[w], k ) <= lu ) & ( lu <= ByteOf( u1[w], k ) ) & ( ByteOf( v0[w], k ) <= lv ) & ( lv <= ByteOf( v1[w], k ) ) & ( ByteOf( far[w], k ) >= reach );
+        hits |= in ? 1u << s : 0u;
+    }
+    const uint32_t imask = ( w1 >> 16 ) & 0xFFu, lmask = w1 >> 24;
+    return WideGroup{ __float_as_uint( n0.z ), __float_as_uint( n0.w ), ( hits & imask ) | imask << 8 | ( hits & lmask ) << 16 | lmask << 24 };
+}
+
+// ConnectWideKernel< true, true > over those records: the same stack, lists and scheduling; a lane keeps its ray as two
+// cells, the start along the main axis and the origin (for the primitive tests, which run in world space as ever).
+__global__ __launch_bounds__( kWideBlock ) __attribute__( ( amdgpu_waves_per_eu( PT_WIDE_WAVES, PT_WIDE_WAVES ) ) )
+void ConnectLightWideKernel( SceneView sv, PathBuffers pb, int bounce, uint2* spill, uint64_t* stats )
+{
+    constexpr uint32_t kThreads = kWideBlock;
+    UnitStream stream{ pb.cursors + 2 * bounce + 1, UnitCount( pb, bounce, kCountShadowRays, 0 ), pb.units, kUnitPaths * pb.shadowSlots, 0u };
+    const uint32_t entries = pb.units * kUnitPaths;
+    const BufferDesc nodes = MakeBuffer( sv.lightWideNodes, sv.numWideNodes * 64u ), prims = MakeBuffer( sv.widePrims, sv.numPrims * 64u );
+    __shared__ uint2 stackLds[kWideLdsStack * kThreads];
+    uint2* const myLds = stackLds + threadIdx.x;
+    __shared__ uint2 leafLds[kLightWideDeferred * kThreads];
+    uint2* const myLeaves = leafLds + threadIdx.x;
+    uint32_t numLeaves = 0;
+    const size_t spillStride = static_cast< size_t >( gridDim.x ) * kThreads, spillLane = static_cast< size_t >( blockIdx.x ) * kThreads + threadIdx.x;
+    uint32_t rec = kNoRay;
+    const f3 d    = F3( pb.shadowDir[0], pb.shadowDir[1], pb.shadowDir[2] );
+    const f3 inv  = F3( 1.0f / d.x, 1.0f / d.y, 1.0f / d.z ); // bvh.cpp:275-276
+    const bool nx = inv.x < 0, ny = inv.y < 0, nz = inv.z < 0;
+    constexpr float tMax = FLT_MAX;                            // src/lights.cpp:35
+    const f3 axisU = F3( sv.lightU ), axisV = F3( sv.lightV );
+    f3 o = F3( 0.0f, 0.0f, 0.0f );
+    uint32_t cellU = 0, cellV = 0;
+    float pw = 0.0f;
+    bool occluded = false;
+    uint32_t sp = 0;
+    uint32_t waveRays = 0, waveNodes = 0, waveTris = 0, waveSpheres = 0, waveSteps = 0; // whole-wave totals, wave-uniform
+
+    for ( ;; )
+    {
+        const bool idle = ( numLeaves | sp ) == 0;
+        const unsigned long long mLeaf = Ballot( numLeaves != 0 ), mIdle = Ballot( idle );
+        const unsigned long long mTrav = Ballot( sp != 0 ) & Ballot( numLeaves < kLightWideDeferred );
+        const unsigned long long mRay  = mIdle & ( stream.ended ? Ballot( rec != kNoRay ) : ~0ull );
+        if ( ( mLeaf | mTrav | mRay ) == 0 ) break;
+
+        if ( mRay && ( __popcll( mRay ) >= PT_LIGHT_WIDE_REFILL_LANES || ( mTrav | mLeaf ) == 0 ) )
+        {
+            if ( idle && rec != kNoRay && !occluded )
+            {
+                const float4 e = pb.shEst[rec];
+                const uint32_t p = __float_as_uint( e.w );
+                pb.rad[p] = F4( F3( pb.rad[p] ) + F3( e ), 0.0f );
+            }
+            if ( idle ) rec = kNoRay;
+            while ( !stream.ended )
+            {
+                const unsigned long long mAsk = Ballot( idle && rec == kNoRay );
+                if ( mAsk == 0 ) break;
+                if ( stream.taken == stream.count )
+                {
+                    NextUnit( stream );
+                    continue;
+                }
+                const uint32_t left = stream.count - stream.taken, asking = static_cast< uint32_t >( __popcll( mAsk ) );
+                const uint32_t rank = LanesBelow( mAsk );
+                if ( idle && rec == kNoRay && rank < left )
+                {
+                    rec = pb.shadowRays[stream.base + stream.taken + rank];
+                    const uint32_t entry = pb.shadowSlots == 1 ? rec : rec % entries; // record index = slot * entries + entry
+                    o = F3( pb.shadowO[entry] );
+                    // the cell the ray's point falls into, as in ConnectParallelKernel (cells 0 and 65535 lie outside every rectangle)
+                    const float gu = ( Dot( o, axisU ) - sv.shadowOrigin[0] ) * sv.shadowInvCell[0];
+                    const float gv = ( Dot( o, axisV ) - sv.shadowOrigin[1] ) * sv.shadowInvCell[1];
+                    cellU = static_cast< uint32_t >( __builtin_fminf( __builtin_fmaxf( gu, 0.0f ), 65535.0f ) );
+                    cellV = static_cast< uint32_t >( __builtin_fminf( __builtin_fmaxf( gv, 0.0f ), 65535.0f ) );
+                    pw = ( sv.shadowDepthAxis == 0 ? o.x : sv.shadowDepthAxis == 1 ? o.y : o.z ) * sv.shadowDepthSign;
+                    occluded = false;
+                    sp       = 1u;
+                    myLds[0] = make_uint2( 0u, 0x0101u ); // the root as the one child of a node above it
+                }
+                const uint32_t given = asking < left ? asking : left;
+                stream.taken += given;
+                waveRays += given;
+            }
+            continue;
+        }
+
+        if ( mLeaf && ( __popcll( mLeaf ) >= PT_LIGHT_WIDE_LEAF_LANES || mTrav == 0 ) )
+        {
+            do
+            {
+                bool isTri = false, isSphere = false;
+                if ( numLeaves != 0 )
+                {
+                    uint2 g = myLeaves[( numLeaves - 1u ) * kThreads];
+                    const uint32_t k = static_cast< uint32_t >( __builtin_ctz( g.y & 0xFFu ) );
+                    g.y &= ~( 1u << k );
+                    if ( ( g.y & 0xFFu ) == 0 )
+                        numLeaves--;
+                    else
+                        myLeaves[( numLeaves - 1u ) * kThreads].y = g.y;
+                    if ( AnyPrimTestWide( prims, g.x + __popc( ( g.y >> 8 ) & ( ( 1u << k ) - 1u ) ), o, d, inv, nx, ny, nz, tMax, &isSphere ) )
+                    {
+                        occluded  = true; // bvh.cpp:287-293: stop at the first hit
+                        numLeaves = 0;
+                        sp        = 0;
+                    }
+                    isTri = !isSphere;
+                }
+                waveTris += LanesSet( isTri );
+                waveSpheres += LanesSet( isSphere );
+            } while ( LanesSet( numLeaves != 0 ) >= PT_LIGHT_WIDE_KEEP_LANES );
+            continue;
+        }
+
+        const uint32_t started = static_cast< uint32_t >( __popcll( mTrav ) );
+        for ( int burst = 0; burst < PT_LIGHT_WIDE_BURST; ++burst )
+        {
+            const bool go = sp != 0 && numLeaves < kLightWideDeferred;
+            const uint32_t active = LanesSet( go );
+            if ( burst && 2 * active < started ) break;
+            waveNodes += active;
+            waveSteps++;
+            if ( go )
+            {
+                const uint32_t top = sp - 1u;
+                uint2 e = myLds[( top < kWideLdsStack ? top : kWideLdsStack - 1u ) * kThreads];
+                asm volatile( "" : "+v"( e.x ), "+v"( e.y ) ); // the LDS read stays an LDS read
+                if ( top >= kWideLdsStack ) e = spill[( top - kWideLdsStack ) * spillStride + spillLane];
+                const uint32_t s = static_cast< uint32_t >( __builtin_ctz( e.y & 0xFFu ) ); // any hit: the order is free
+                const uint32_t left = e.y & ~( 1u << s );
+                if ( ( left & 0xFFu ) == 0 )
+                    sp = top;
+                else if ( top < kWideLdsStack )
+                    myLds[top * kThreads].y = left;
+                else
+                    spill[( top - kWideLdsStack ) * spillStride + spillLane].y = left;
+                const WideGroup g = LightWideVisit( nodes, e.x + __popc( ( e.y >> 8 ) & ( ( 1u << s ) - 1u ) ), cellU, cellV, pw );
+                if ( g.bits & 0xFF0000u ) myLeaves[numLeaves++ * kThreads] = make_uint2( g.primBase, g.bits >> 16 );
+                if ( g.bits & 0xFFu )
+                {
+                    if ( sp < kWideLdsStack )
+                        myLds[sp * kThreads] = make_uint2( g.childBase, g.bits & 0xFFFFu );
+                    else
+                        spill[( sp - kWideLdsStack ) * spillStride + spillLane] = make_uint2( g.childBase, g.bits & 0xFFFFu );
+                    sp++;
+                }
+            }
+        }
+    }
+    FlushWaveCounter( stats, ST_RAYS_SHADOW, waveRays );
+    FlushWaveCounter( stats, ST_NODES_SHADOW, waveNodes );
+    FlushWaveCounter( stats, ST_TRI_SHADOW, waveTris );
+    FlushWaveCounter( stats, ST_SPH_SHADOW, waveSpheres );
+    FlushWaveCounter( stats, ST_STEPS_SHADOW, waveSteps );
+}
+
 // Shadow rays of a scene lit by one directional light (src/lights.cpp:25-38): they all have the light's direction,
 // so BVH::Occluded (src/bvh.cpp:270-310) becomes a search in two dimensions.  Seen along the light's direction - lightU
 // and lightV are two axes across it - a ray is a point, a node the rectangle around its geometry, and the node can
@@ -2538,7 +2744,9 @@ void LaunchConnect( const LaunchCfg& cfg, const SceneView& sv, const PathBuffers
 {
     if ( cfg.wideShadows )
     {
-        if ( pb.directSum && pb.constantShadowDir )
+        if ( pb.directSum && pb.constantShadowDir && sv.lightWideNodes )
+            hipLaunchKernelGGL( ConnectLightWideKernel, dim3( cfg.wideShadowBlocks ), dim3( kWideBlock ), 0, cfg.stream, sv, pb, bounce, cfg.wideSpill, stats );
+        else if ( pb.directSum && pb.constantShadowDir )
             hipLaunchKernelGGL( ( ConnectWideKernel< true, true > ), dim3( cfg.wideShadowBlocks ), dim3( kWideBlock ), 0, cfg.stream, sv, pb, bounce, cfg.wideSpill, stats );
         else if ( pb.directSum )
             hipLaunchKernelGGL( ( ConnectWideKernel< true > ), dim3( cfg.wideShadowBlocks ), dim3( kWideBlock ), 0, cfg.stream, sv, pb, bounce, cfg.wideSpill, stats );

@@ -69,4 +69,12 @@ void CountShadowRecords( hipStream_t stream, const LayoutInputs& in, const uint3
 void BuildShadowRecords( hipStream_t stream, const LayoutInputs& in, const float* frame, const ShadowGrid& grid, const uint32_t* topSorted, const uint32_t* topRank,
                          uint32_t topCount, const uint32_t* before, uint4* rec, uint32_t* topWords );
 
+// The wide layout once more for the shadow rays of the one directional light (ConnectLightWideKernel in kernels.hip):
+// 64-byte records, one per wide node and with the same indices, of the children's rectangles on the light's grid and
+// their reach along the rays' main axis (see LightWideNodesKernel).  primRect ( 8 bytes ), primFar ( 4 bytes ) per
+// primitive, parent, arrivals ( 4 bytes ) and nodeBounds ( 16 bytes ) per wide node are scratch; verdict: one word, 0
+// afterwards, or kShadowFramesWrong: the records must not be used.
+void BuildLightWideNodes( hipStream_t stream, const LayoutInputs& in, const ShadowAxes& axes, const ShadowGrid& grid, const void* wideNodes, uint32_t numWideNodes,
+                          const float4* widePrims, uint2* primRect, float* primFar, uint32_t* parent, uint32_t* arrivals, uint32_t* nodeBounds, uint32_t* verdict, uint4* out );
+
 } // namespace ptd

@@ -306,6 +306,42 @@ __global__ __launch_bounds__( kBlock ) void ParentsKernel( LayoutInputs in, uint
     parent[static_cast< uint32_t >( n.offset )] = x;
 }
 
+// lo, hi <- joined with the extent of one primitive along the two axes of the light's frame, in double precision (the
+// products of two floats are exact there, so the sums are the host's whether fused or not)
+__device__ __forceinline__ void JoinPrimitive( const LayoutInputs& in, const ShadowAxes& axes, PtPrim prim, double lo[2], double hi[2] )
+{
+    if ( prim.type == PT_PRIM_TRIANGLE )
+    {
+        const PtTriangle t = in.triangles[prim.index];
+        const PtMesh m     = in.meshes[t.mesh];
+        const uint32_t idx[3] = { t.i0, t.i1, t.i2 };
+        for ( int c = 0; c < 3; ++c )
+        {
+            const float* p = VertexOf( in.vertices, m, idx[c], 3 );
+            for ( int a = 0; a < 2; ++a )
+            {
+                const float* ax = a ? axes.v : axes.u;
+                const double q = static_cast< double >( p[0] ) * ax[0] + static_cast< double >( p[1] ) * ax[1] + static_cast< double >( p[2] ) * ax[2];
+                lo[a] = q < lo[a] ? q : lo[a];
+                hi[a] = hi[a] < q ? q : hi[a];
+            }
+        }
+    }
+    else
+    {
+        const PtSphere sp = in.spheres[prim.index];
+        for ( int a = 0; a < 2; ++a )
+        {
+            const float* ax = a ? axes.v : axes.u;
+            const double q   = static_cast< double >( sp.position[0] ) * ax[0] + static_cast< double >( sp.position[1] ) * ax[1] + static_cast< double >( sp.position[2] ) * ax[2];
+            const double len = sqrt( static_cast< double >( ax[0] ) * ax[0] + static_cast< double >( ax[1] ) * ax[1] + static_cast< double >( ax[2] ) * ax[2] );
+            const double r   = fabs( static_cast< double >( sp.radius ) ) * len * ( 1.0 + 1e-6 );
+            lo[a] = q - r < lo[a] ? q - r : lo[a];
+            hi[a] = hi[a] < q + r ? q + r : hi[a];
+        }
+    }
+}
+
 // Bounds of every node in the light's frame {u0, u1, v0, v1}, from the geometry below it: a leaf from its primitives, then
 // up the tree - the second child to arrive at a parent finds its sibling's bounds written and goes on, the first leaves.
 // The bounds travel between the two through agent-scope atomic stores and loads, which go past this XCD's L2 to memory, and
@@ -322,40 +358,7 @@ __global__ __launch_bounds__( kBlock ) void ShadowFramesKernel( LayoutInputs in,
     const PtBvhNode n = in.nodes[i];
     if ( n.num_shapes == 0 ) return;
     double lo[2] = { INFINITY, INFINITY }, hi[2] = { -INFINITY, -INFINITY };
-    for ( uint32_t k = 0; k < n.num_shapes; ++k )
-    {
-        const PtPrim prim = in.prims[static_cast< uint64_t >( n.offset ) + k];
-        if ( prim.type == PT_PRIM_TRIANGLE )
-        {
-            const PtTriangle t = in.triangles[prim.index];
-            const PtMesh m     = in.meshes[t.mesh];
-            const uint32_t idx[3] = { t.i0, t.i1, t.i2 };
-            for ( int c = 0; c < 3; ++c )
-            {
-                const float* p = VertexOf( in.vertices, m, idx[c], 3 );
-                for ( int a = 0; a < 2; ++a )
-                {
-                    const float* ax = a ? axes.v : axes.u;
-                    const double q = static_cast< double >( p[0] ) * ax[0] + static_cast< double >( p[1] ) * ax[1] + static_cast< double >( p[2] ) * ax[2];
-                    lo[a] = q < lo[a] ? q : lo[a];
-                    hi[a] = hi[a] < q ? q : hi[a];
-                }
-            }
-        }
-        else
-        {
-            const PtSphere sp = in.spheres[prim.index];
-            for ( int a = 0; a < 2; ++a )
-            {
-                const float* ax = a ? axes.v : axes.u;
-                const double q   = static_cast< double >( sp.position[0] ) * ax[0] + static_cast< double >( sp.position[1] ) * ax[1] + static_cast< double >( sp.position[2] ) * ax[2];
-                const double len = sqrt( static_cast< double >( ax[0] ) * ax[0] + static_cast< double >( ax[1] ) * ax[1] + static_cast< double >( ax[2] ) * ax[2] );
-                const double r   = fabs( static_cast< double >( sp.radius ) ) * len * ( 1.0 + 1e-6 );
-                lo[a] = q - r < lo[a] ? q - r : lo[a];
-                hi[a] = hi[a] < q + r ? q + r : hi[a];
-            }
-        }
-    }
+    for ( uint32_t k = 0; k < n.num_shapes; ++k ) JoinPrimitive( in, axes, in.prims[static_cast< uint64_t >( n.offset ) + k], lo, hi );
     float f[4] = { RoundedDown( lo[0] ), RoundedUp( hi[0] ), RoundedDown( lo[1] ), RoundedUp( hi[1] ) };
     for ( uint32_t y = i;; )
     {
@@ -470,6 +473,23 @@ __global__ __launch_bounds__( kBlock ) void PrefixTilesKernel( uint32_t* __restr
     }
 }
 
+// The rectangle {u0, u1, v0, v1} on the grid, widened by the slack: q[a] = first cell | ( last cell - first cell ) << 16 along axis a
+__device__ __forceinline__ void CellsOfFrame( const float* f, const ShadowGrid& grid, uint32_t q[2] )
+{
+    for ( int a = 0; a < 2; ++a )
+    {
+        const double lo = f[2 * a], hi = f[2 * a + 1];
+        // std::min( 65534.0, std::max( 1.0, . ) ) and std::min( 65534.0, std::max( qlo, . ) ), comparisons in their order
+        double qlo = floor( ( lo - grid.origin[a] ) / grid.cell[a] - grid.slack[a] );
+        qlo = 1.0 < qlo ? qlo : 1.0;
+        qlo = qlo < 65534.0 ? qlo : 65534.0;
+        double qhi = floor( ( hi - grid.origin[a] ) / grid.cell[a] + grid.slack[a] );
+        qhi = qlo < qhi ? qhi : qlo;
+        qhi = qhi < 65534.0 ? qhi : 65534.0;
+        q[a] = static_cast< uint32_t >( qlo ) | static_cast< uint32_t >( qhi - qlo ) << 16;
+    }
+}
+
 __global__ __launch_bounds__( kBlock ) void ShadowRecordsKernel( LayoutInputs in, const float* __restrict__ frame, ShadowGrid grid, const uint32_t* __restrict__ topSorted,
                                                                  const uint32_t* __restrict__ topRank, uint32_t topCount, const uint32_t* __restrict__ before,
                                                                  uint4* __restrict__ rec, uint32_t* __restrict__ topWords )
@@ -483,19 +503,7 @@ __global__ __launch_bounds__( kBlock ) void ShadowRecordsKernel( LayoutInputs in
     };
     const PtBvhNode n = in.nodes[i];
     uint32_t q[2];
-    const float* f = frame + 4ull * i;
-    for ( int a = 0; a < 2; ++a )
-    {
-        const double lo = f[2 * a], hi = f[2 * a + 1];
-        // std::min( 65534.0, std::max( 1.0, . ) ) and std::min( 65534.0, std::max( qlo, . ) ), comparisons in their order
-        double qlo = floor( ( lo - grid.origin[a] ) / grid.cell[a] - grid.slack[a] );
-        qlo = 1.0 < qlo ? qlo : 1.0;
-        qlo = qlo < 65534.0 ? qlo : 65534.0;
-        double qhi = floor( ( hi - grid.origin[a] ) / grid.cell[a] + grid.slack[a] );
-        qhi = qlo < qhi ? qhi : qlo;
-        qhi = qhi < 65534.0 ? qhi : 65534.0;
-        q[a] = static_cast< uint32_t >( qlo ) | static_cast< uint32_t >( qhi - qlo ) << 16;
-    }
+    CellsOfFrame( frame + 4ull * i, grid, q );
     const float wmax = grid.towardsPositive ? n.aabb_max[grid.depthAxis] : -n.aabb_min[grid.depthAxis];
     const bool leaf     = n.num_shapes > 0;
     const uint32_t next = in.escape[i];
@@ -507,6 +515,197 @@ __global__ __launch_bounds__( kBlock ) void ShadowRecordsKernel( LayoutInputs in
         topWords[at] = leaf ? link : recordOf( i + 1 );
     else if ( leaf && next < in.numNodes && link < grid.shadowTop )
         rec[at + 1] = make_uint4( 1u, 1u, __float_as_uint( -INFINITY ), link ); // no ray enters it; it links back into the top
+}
+
+// ---- the wide tree in the light's frame (the records ConnectLightWideKernel reads, see kernels.hip)
+//
+// Same nodes, same children, same indices as the wide layout (wide_bvh.h); what a record holds of a child is the rectangle
+// around its geometry on the light's grid and how far it reaches along the rays' main axis - outer bounds both, joined
+// upwards from the primitives: a primitive's rectangle is CellsOfFrame of its own extent, its reach the far plane of its
+// leaf's box (what the third layout keeps per leaf).
+
+struct LightBounds
+{
+    uint32_t x0, x1, y0, y1; // cells
+    float farMax, farMin;    // largest and smallest reach of a child
+};
+
+__device__ __forceinline__ void Join( LightBounds& b, uint32_t rx, uint32_t ry, float farMax, float farMin )
+{
+    const uint32_t x0 = rx & 0xFFFFu, x1 = rx >> 16, y0 = ry & 0xFFFFu, y1 = ry >> 16;
+    b.x0 = x0 < b.x0 ? x0 : b.x0; b.x1 = b.x1 < x1 ? x1 : b.x1;
+    b.y0 = y0 < b.y0 ? y0 : b.y0; b.y1 = b.y1 < y1 ? y1 : b.y1;
+    b.farMax = b.farMax < farMax ? farMax : b.farMax;
+    b.farMin = farMin < b.farMin ? farMin : b.farMin;
+}
+
+struct WideChildren
+{
+    uint32_t imask, lmask, childBase, primBase;
+};
+__device__ __forceinline__ WideChildren ChildrenOf( const uint32_t* __restrict__ wideNodes, uint32_t n )
+{
+    const uint32_t* w = wideNodes + 20ull * n;
+    return WideChildren{ w[3] >> 24, w[6] & 0xFFu, w[4], w[5] };
+}
+
+__device__ __forceinline__ uint32_t LoadSharedWord( const uint32_t* p ) { return __hip_atomic_load( p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ); }
+
+// A node's bounds: {x0 | x1 << 16, y0 | y1 << 16, farMax, farMin}.  kShared: the children's bounds were written by other
+// threads of this launch (LightClimbKernel)
+template < bool kShared >
+__device__ __forceinline__ uint4 BoundsOfNode( const WideChildren& c, const uint2* __restrict__ primRect, const float* __restrict__ primFar, const uint32_t* nodeBounds )
+{
+    LightBounds b{ 0xFFFFu, 0u, 0xFFFFu, 0u, -INFINITY, INFINITY };
+    for ( uint32_t k = 0, count = __popc( c.lmask ); k < count; ++k )
+    {
+        const uint2 r = primRect[c.primBase + k];
+        const float f = primFar[c.primBase + k];
+        Join( b, r.x, r.y, f, f );
+    }
+    for ( uint32_t k = 0, count = __popc( c.imask ); k < count; ++k )
+    {
+        const uint32_t* w = nodeBounds + 4ull * ( c.childBase + k );
+        uint32_t rx, ry, fmax;
+        if constexpr ( kShared )
+        {
+            rx   = LoadSharedWord( w );
+            ry   = LoadSharedWord( w + 1 );
+            fmax = LoadSharedWord( w + 2 );
+        }
+        else
+        {
+            rx   = w[0];
+            ry   = w[1];
+            fmax = w[2];
+        }
+        Join( b, rx, ry, __uint_as_float( fmax ), __uint_as_float( fmax ) ); // a child reaches as far as its farthest child
+    }
+    return make_uint4( b.x0 | b.x1 << 16, b.y0 | b.y1 << 16, __float_as_uint( b.farMax ), __float_as_uint( b.farMin ) );
+}
+
+// One thread per primitive of the wide layout's copy: word 3 of its record names it in the reference's order, words 7, 11,
+// 12 - 15 are its leaf's box
+__global__ __launch_bounds__( kBlock ) void LightPrimBoundsKernel( LayoutInputs in, ShadowAxes axes, ShadowGrid grid, const float4* __restrict__ widePrims,
+                                                                   uint2* __restrict__ primRect, float* __restrict__ primFar )
+{
+    const uint32_t j = GlobalIndex();
+    if ( j >= in.numPrims ) return;
+    const float4 q0 = widePrims[4ull * j], q1 = widePrims[4ull * j + 1], q2 = widePrims[4ull * j + 2], q3 = widePrims[4ull * j + 3];
+    double lo[2] = { INFINITY, INFINITY }, hi[2] = { -INFINITY, -INFINITY };
+    JoinPrimitive( in, axes, in.prims[__float_as_uint( q0.w ) & 0x7FFFFFFFu], lo, hi );
+    const float f[4] = { RoundedDown( lo[0] ), RoundedUp( hi[0] ), RoundedDown( lo[1] ), RoundedUp( hi[1] ) };
+    uint32_t q[2];
+    CellsOfFrame( f, grid, q );
+    primRect[j] = make_uint2( ( q[0] & 0xFFFFu ) | ( ( q[0] & 0xFFFFu ) + ( q[0] >> 16 ) ) << 16, ( q[1] & 0xFFFFu ) | ( ( q[1] & 0xFFFFu ) + ( q[1] >> 16 ) ) << 16 );
+    const float boxLo[3] = { q1.w, q2.w, q3.x }, boxHi[3] = { q3.y, q3.z, q3.w };
+    primFar[j] = grid.towardsPositive ? boxHi[grid.depthAxis] : -boxLo[grid.depthAxis];
+}
+
+__global__ __launch_bounds__( kBlock ) void WideParentsKernel( const uint32_t* __restrict__ wideNodes, uint32_t numNodes, uint32_t* __restrict__ parent )
+{
+    const uint32_t n = GlobalIndex();
+    if ( n >= numNodes ) return;
+    if ( n == 0 ) parent[0] = kUnset;
+    const WideChildren c = ChildrenOf( wideNodes, n );
+    for ( uint32_t k = 0, count = __popc( c.imask ); k < count; ++k ) parent[c.childBase + k] = n;
+}
+
+// Bounds of every wide node, joined upwards: the nodes without inner children start, and whoever arrives last at a parent
+// does the parent (the protocol of ShadowFramesKernel< false >; LightBoundsCheckKernel proves the result)
+__global__ __launch_bounds__( kBlock ) void LightClimbKernel( const uint32_t* __restrict__ wideNodes, uint32_t numNodes, const uint32_t* __restrict__ parent,
+                                                              uint32_t* __restrict__ arrivals, const uint2* __restrict__ primRect, const float* __restrict__ primFar,
+                                                              uint32_t* nodeBounds )
+{
+    const uint32_t i = GlobalIndex();
+    if ( i >= numNodes ) return;
+    WideChildren c = ChildrenOf( wideNodes, i );
+    if ( c.imask != 0 ) return;
+    for ( uint32_t n = i;; )
+    {
+        const uint4 b = BoundsOfNode< true >( c, primRect, primFar, nodeBounds );
+        uint32_t* mine = nodeBounds + 4ull * n;
+        __hip_atomic_store( mine, b.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+        __hip_atomic_store( mine + 1, b.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+        __hip_atomic_store( mine + 2, b.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+        __hip_atomic_store( mine + 3, b.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+        const uint32_t p = parent[n];
+        if ( p == kUnset ) break;
+        c = ChildrenOf( wideNodes, p );
+        __builtin_amdgcn_fence( __ATOMIC_RELEASE, "workgroup" ); // waits for the stores' acknowledgements
+        if ( atomicAdd( arrivals + p, 1u ) + 1u != static_cast< uint32_t >( __popc( c.imask ) ) ) break; // others are still on their way
+        __builtin_amdgcn_fence( __ATOMIC_ACQUIRE, "workgroup" );
+        n = p;
+    }
+}
+
+__global__ __launch_bounds__( kBlock ) void LightBoundsCheckKernel( const uint32_t* __restrict__ wideNodes, uint32_t numNodes, const uint2* __restrict__ primRect,
+                                                                    const float* __restrict__ primFar, const uint32_t* __restrict__ nodeBounds, uint32_t* __restrict__ verdict )
+{
+    const uint32_t n = GlobalIndex();
+    if ( n >= numNodes ) return;
+    const uint4 b = BoundsOfNode< false >( ChildrenOf( wideNodes, n ), primRect, primFar, nodeBounds );
+    const uint32_t* w = nodeBounds + 4ull * n;
+    if ( b.x != w[0] || b.y != w[1] || b.z != w[2] || b.w != w[3] ) atomicOr( verdict, kShadowFramesWrong );
+}
+
+// The 64-byte record of a wide node in the light's frame:
+//   0      first cell of the node's rectangle along u | along v << 16
+//   1      shiftU | shiftV << 8 | imask << 16 | lmask << 24: a child's rectangle is kept in units of 2^shift cells from there
+//   2, 3   index of the first inner child, of the first primitive (as in the wide layout)
+//   4, 5   d0, 1 / step: a child reaches to d0 + byte * step along the rays' main axis, rounded up
+//   6, 7   reach[8];  8, 9  first u[8];  10, 11  last u[8];  12, 13  first v[8];  14, 15  last v[8] - one byte per slot; an
+//          empty slot has first = 255, last = 0
+__global__ __launch_bounds__( kBlock ) void LightWideNodesKernel( const uint32_t* __restrict__ wideNodes, uint32_t numNodes, const uint2* __restrict__ primRect,
+                                                                  const float* __restrict__ primFar, const uint32_t* __restrict__ nodeBounds, uint4* __restrict__ out )
+{
+    const uint32_t n = GlobalIndex();
+    if ( n >= numNodes ) return;
+    const WideChildren c = ChildrenOf( wideNodes, n );
+    const uint32_t* w = nodeBounds + 4ull * n;
+    const uint32_t ox = w[0] & 0xFFFFu, oy = w[1] & 0xFFFFu, ex = ( w[0] >> 16 ) - ox, ey = ( w[1] >> 16 ) - oy;
+    const uint32_t shiftU = ex > 255u ? 24u - __clz( ex ) : 0u, shiftV = ey > 255u ? 24u - __clz( ey ) : 0u; // extent >> shift <= 255
+    const double d0 = __uint_as_float( w[3] ), range = static_cast< double >( __uint_as_float( w[2] ) ) - d0;
+    int e = 0;
+    if ( range > 0.0 )
+    {
+        (void)frexp( range / 255.0, &e ); // range / 255 = m * 2^e with m < 1: 2^e is a step that 255 of reach over the range
+        e = e < -126 ? -126 : e;
+    }
+    const double step = ldexp( 1.0, e );
+    uint32_t bytes[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }; // reach, first u, last u, first v, last v: two words each
+    for ( uint32_t s = 0; s < 8; ++s )
+    {
+        uint32_t reach = 0, u0 = 255, u1 = 0, v0 = 255, v1 = 0;
+        const uint32_t bit = 1u << s;
+        if ( ( c.imask | c.lmask ) & bit )
+        {
+            uint32_t rx, ry;
+            float far;
+            if ( c.imask & bit )
+            {
+                const uint32_t* cw = nodeBounds + 4ull * ( c.childBase + __popc( c.imask & ( bit - 1u ) ) );
+                rx = cw[0]; ry = cw[1]; far = __uint_as_float( cw[2] );
+            }
+            else
+            {
+                const uint32_t j = c.primBase + __popc( c.lmask & ( bit - 1u ) );
+                rx = primRect[j].x; ry = primRect[j].y; far = primFar[j];
+            }
+            u0 = ( ( rx & 0xFFFFu ) - ox ) >> shiftU; u1 = ( ( rx >> 16 ) - ox ) >> shiftU;
+            v0 = ( ( ry & 0xFFFFu ) - oy ) >> shiftV; v1 = ( ( ry >> 16 ) - oy ) >> shiftV;
+            reach = static_cast< uint32_t >( ceil( ( static_cast< double >( far ) - d0 ) / step ) ); // <= 255 by the choice of the step
+        }
+        const uint32_t at = s >> 2, sh = 8u * ( s & 3u );
+        bytes[at] |= reach << sh;
+        bytes[2 + at] |= u0 << sh; bytes[4 + at] |= u1 << sh;
+        bytes[6 + at] |= v0 << sh; bytes[8 + at] |= v1 << sh;
+    }
+    uint4* o = out + 4ull * n;
+    o[0] = make_uint4( ox | oy << 16, shiftU | shiftV << 8 | c.imask << 16 | c.lmask << 24, c.childBase, c.primBase );
+    o[1] = make_uint4( __float_as_uint( static_cast< float >( d0 ) ), __float_as_uint( static_cast< float >( 1.0 / step ) ), bytes[0], bytes[1] );
+    o[2] = make_uint4( bytes[2], bytes[3], bytes[4], bytes[5] );
+    o[3] = make_uint4( bytes[6], bytes[7], bytes[8], bytes[9] );
 }
 
 } // namespace
@@ -575,6 +774,22 @@ void BuildShadowRecords( hipStream_t stream, const LayoutInputs& in, const float
 {
     if ( in.numNodes == 0 ) return;
     hipLaunchKernelGGL( ShadowRecordsKernel, dim3( BlocksFor( in.numNodes ) ), dim3( kBlock ), 0, stream, in, frame, grid, topSorted, topRank, topCount, before, rec, topWords );
+}
+
+
+void BuildLightWideNodes( hipStream_t stream, const LayoutInputs& in, const ShadowAxes& axes, const ShadowGrid& grid, const void* wideNodes, uint32_t numWideNodes,
+                          const float4* widePrims, uint2* primRect, float* primFar, uint32_t* parent, uint32_t* arrivals, uint32_t* nodeBounds, uint32_t* verdict, uint4* out )
+{
+    if ( numWideNodes == 0 || in.numPrims == 0 ) return;
+    const uint32_t* nodes = static_cast< const uint32_t* >( wideNodes );
+    const dim3 perNode( BlocksFor( numWideNodes ) ), perPrim( BlocksFor( static_cast< uint32_t >( in.numPrims ) ) ), block( kBlock );
+    (void)hipMemsetAsync( verdict, 0, 4, stream );
+    (void)hipMemsetAsync( arrivals, 0, 4ull * numWideNodes, stream );
+    hipLaunchKernelGGL( LightPrimBoundsKernel, perPrim, block, 0, stream, in, axes, grid, widePrims, primRect, primFar );
+    hipLaunchKernelGGL( WideParentsKernel, perNode, block, 0, stream, nodes, numWideNodes, parent );
+    hipLaunchKernelGGL( LightClimbKernel, perNode, block, 0, stream, nodes, numWideNodes, parent, arrivals, primRect, primFar, nodeBounds );
+    hipLaunchKernelGGL( LightBoundsCheckKernel, perNode, block, 0, stream, nodes, numWideNodes, primRect, primFar, nodeBounds, verdict );
+    hipLaunchKernelGGL( LightWideNodesKernel, perNode, block, 0, stream, nodes, numWideNodes, primRect, primFar, nodeBounds, out );
 }
 
 } // namespace ptd

@@ -75,6 +75,7 @@ struct SceneView
     const float4* wideNodes;    // fourth layout (wide_bvh.h): 5 x float4 per node of up to eight children, or nullptr
     const float4* widePrims;    // the primitive records in the order the wide nodes refer to them
     uint32_t numWideNodes;
+    const float4* lightWideNodes; // the wide nodes in the frame of the one directional light: 4 x float4 per node, same indices, or nullptr
     uint32_t wideDepth;         // levels of wide nodes: the deepest a traversal stack can get
     const float4* prims;
     const float4* triShade;

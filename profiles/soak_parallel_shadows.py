@@ -1,6 +1,7 @@
 """Soak for the light-space shadow rays: random light directions (a share of them almost along an axis or with tiny
-components), random translations and scales of the fixture scenes; the film front to back must equal the film in the
-reference's order bit for bit.  usage: python3 profiles/soak_parallel_shadows.py [--cases N]"""
+components), random translations and scales of the fixture scenes; the film front to back, and the film over the wide
+layout (whose shadow rays run over the wide nodes in the light's frame), must equal the film in the reference's order bit
+for bit.  usage: python3 profiles/soak_parallel_shadows.py [--cases N]"""
 import argparse, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,7 +14,7 @@ p.add_argument("--cases", type=int, default=300)
 a = p.parse_args()
 rng = np.random.default_rng(20261111)
 scenes = {n: SceneData.load(os.path.join(ROOT, "tests", "golden", f"{n}_scene.npz")) for n in ("cornell", "mixed")}
-bad = 0
+bad = with_wide = 0
 for case in range(a.cases):
     name = ("cornell", "mixed")[case % 2]
     s = scenes[name].with_image(32, 32, 1.0)
@@ -58,9 +59,13 @@ for case in range(a.cases):
         dev.render(4, seed=case, ordered=True)
         fast = dev.download_film()
         st = dev.stats()
-    same = np.array_equal(ref.view(np.uint32), fast.view(np.uint32))
-    if not same:
-        bad += 1
-        print(f"case {case} ({name}, light {rec['direction'][0].tolist()}): {(ref.view(np.uint32) != fast.view(np.uint32)).any(-1).sum()} pixels differ", flush=True)
-print(f"{a.cases} cases, {bad} with a differing film", flush=True)
+        dev.render(4, seed=case, wide=True, wide_shadows=True)   # shadow rays over the wide nodes in the light's frame
+        wide = dev.download_film()
+        have_wide = len(dev.read_layout(abi.PT_LAYOUT_LIGHT_WIDE_NODES)) > 0
+    with_wide += have_wide
+    for what, film in (("front to back", fast), ("wide", wide)):
+        if not np.array_equal(ref.view(np.uint32), film.view(np.uint32)):
+            bad += 1
+            print(f"case {case} ({name}, light {rec['direction'][0].tolist()}), {what}: {(ref.view(np.uint32) != film.view(np.uint32)).any(-1).sum()} pixels differ", flush=True)
+print(f"{a.cases} cases ({with_wide} with the wide nodes in the light's frame), {bad} differing films", flush=True)
 sys.exit(1 if bad else 0)

@@ -1,5 +1,5 @@
 """Shadow rays of a scene lit by one directional light, traced in the light's frame (PT_RENDER_ORDERED with the third
-node layout): the film must equal the film of the reference's own traversal bit for bit - every occlusion answer is
+node layout, PT_RENDER_WIDE_SHADOWS with the wide nodes in that frame): the film must equal the film of the reference's own traversal bit for bit - every occlusion answer is
 the reference's - for lights along an axis, oblique and almost along an axis, for leaves of several shapes, spheres,
 geometry far from the origin, and at the size of the benchmark's scene."""
 import numpy as np
@@ -35,7 +35,12 @@ def films(desc, spp, seed):
         reference = dev.download_film()
         ref_stats = dev.stats()   # the counters are those of the last pt_render
         dev.render(spp, seed=seed, ordered=True)
-        return reference, dev.download_film(), ref_stats, dev.stats()
+        fast, st = dev.download_film(), dev.stats()
+        # and over the wide layout, whose shadow rays then run over the wide nodes in the light's frame
+        dev.render(spp, seed=seed, wide=True, wide_shadows=True)
+        assert_bits_equal(dev.download_film(), reference, "wide layout in the light's frame")
+        assert dev.stats().rays_shadow == ref_stats.rays_shadow
+        return reference, fast, ref_stats, st
 
 
 def check(scene, what, spp=8, seed=4, flags=0):
