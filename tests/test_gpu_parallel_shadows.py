@@ -122,3 +122,19 @@ def test_benchmark_scene_at_its_size():
         assert_bits_equal(fast, reference, "atrium 960x540")
         print(f"shadow rays {st.rays_shadow}: nodes per ray {ref_stats.nodes_shadow / ref_stats.rays_shadow:.1f} in the tree, "
               f"{st.nodes_shadow / st.rays_shadow:.1f} in the light's frame")
+
+
+@pytest.mark.parametrize("direction", [(0, -1, 0), (0.3, -0.8, 0.5), (-0.6, 0.2, 0.77)])
+def test_large_trees(direction):
+    """A 2 M triangle soup (4 M nodes, 13 levels of wide nodes) and the knot under one directional light: deep stacks,
+    rectangles of a few cells, nodes whose rectangle takes the largest shift"""
+    from pathtracer_amd import host
+    from test_gpu_layouts import lit_from
+    for make, what in ((lambda: host.HostScene.soup(seed=5, triangles=2_000_000, edge=0.01, skybox_size=64), "soup 2M"),
+                       (lambda: host.HostScene.knot(seed=2, triangles=871414), "knot")):
+        with make() as hs:
+            hs.set_image(512, 512, 1.0)
+            hs.set_max_depth(3)
+            reference, fast, ref_stats, st = films(lit_from(hs, 0, direction), 2, 11)
+            assert_bits_equal(fast, reference, f"{what}, light {direction}")
+            assert ref_stats.rays_shadow > 100000
