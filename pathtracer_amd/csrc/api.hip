@@ -1222,9 +1222,9 @@ int Upload( PtScene* s, const PtSceneDesc* d, const std::vector< uint32_t >& esc
     s->width    = d->image_width;
     s->height   = d->image_height;
     s->maxDepth = d->max_depth;
-    // ray origin, direction and throughput double buffered, hit, radiance, shadow origin (16 B each), four queues
-    // (4 B each), per shadow slot a 32 B record and a 4 B queue entry
-    s->bytesPerPathFixed = 9 * 16 + 5 * 4 + 36ull * static_cast< uint64_t >( slots > 0 ? slots : 1 );
+    // ray origin, direction and throughput double buffered and the shadow origin (12 B each), hit, radiance (16 B each),
+    // four queues (4 B each), per shadow slot a 32 B record and a 4 B queue entry
+    s->bytesPerPathFixed = 7 * 12 + 2 * 16 + 5 * 4 + 36ull * static_cast< uint64_t >( slots > 0 ? slots : 1 );
 
     const size_t pixels = static_cast< size_t >( s->width ) * s->height;
     HIP_TRY( s->film.Allocate( pixels * 16 ) );
@@ -1249,15 +1249,15 @@ int EnsurePathBuffers( PtScene* s, uint64_t capacity )
     // one queue segment of kUnitPaths entries per unit of paths, one length per bounce, queue and unit
     const uint64_t units   = ( capacity + kUnitPaths - 1 ) / kUnitPaths;
     const uint64_t entries = units * kUnitPaths;
-    HIP_TRY( s->rayO0.Allocate( entries * 16 ) );
-    HIP_TRY( s->rayO1.Allocate( entries * 16 ) );
-    HIP_TRY( s->rayD0.Allocate( entries * 16 ) );
-    HIP_TRY( s->rayD1.Allocate( entries * 16 ) );
-    HIP_TRY( s->thr0.Allocate( entries * 16 ) );
-    HIP_TRY( s->thr1.Allocate( entries * 16 ) );
+    HIP_TRY( s->rayO0.Allocate( entries * sizeof( Packed3 ) ) );
+    HIP_TRY( s->rayO1.Allocate( entries * sizeof( Packed3 ) ) );
+    HIP_TRY( s->rayD0.Allocate( entries * sizeof( Packed3 ) ) );
+    HIP_TRY( s->rayD1.Allocate( entries * sizeof( Packed3 ) ) );
+    HIP_TRY( s->thr0.Allocate( entries * sizeof( Packed3 ) ) );
+    HIP_TRY( s->thr1.Allocate( entries * sizeof( Packed3 ) ) );
     HIP_TRY( s->hit.Allocate( entries * 16 ) );
     HIP_TRY( s->rad.Allocate( capacity * 16 ) );
-    HIP_TRY( s->shadowO.Allocate( entries * 16 ) );
+    HIP_TRY( s->shadowO.Allocate( entries * sizeof( Packed3 ) ) );
     HIP_TRY( s->shDir.Allocate( entries * slots * 16 ) );
     HIP_TRY( s->shEst.Allocate( entries * slots * 16 ) );
     HIP_TRY( s->counts.Allocate( kCountsPerBounce * 4 * static_cast< size_t >( s->maxDepth > 0 ? s->maxDepth : 1 ) * units ) );
@@ -1268,13 +1268,13 @@ int EnsurePathBuffers( PtScene* s, uint64_t capacity )
     if ( s->view.numSpheres ) HIP_TRY( s->sphereQueue.Allocate( entries * 4 ) );
     if ( s->orderedNodes.ptr || s->wideNodes.ptr ) HIP_TRY( s->redo.Allocate( entries * 4 ) );
     PathBuffers& p = s->paths;
-    p.rayO[0]     = s->rayO0.As< float4 >();
-    p.rayO[1]     = s->rayO1.As< float4 >();
-    p.rayD[0]     = s->rayD0.As< float4 >();
-    p.rayD[1]     = s->rayD1.As< float4 >();
-    p.shadowO     = s->shadowO.As< float4 >();
-    p.thr[0]      = s->thr0.As< float4 >();
-    p.thr[1]      = s->thr1.As< float4 >();
+    p.rayO[0]     = s->rayO0.As< Packed3 >();
+    p.rayO[1]     = s->rayO1.As< Packed3 >();
+    p.rayD[0]     = s->rayD0.As< Packed3 >();
+    p.rayD[1]     = s->rayD1.As< Packed3 >();
+    p.shadowO     = s->shadowO.As< Packed3 >();
+    p.thr[0]      = s->thr0.As< Packed3 >();
+    p.thr[1]      = s->thr1.As< Packed3 >();
     p.rad         = s->rad.As< float4 >();
     p.hit         = s->hit.As< float4 >();
     p.shDir       = s->shDir.As< float4 >();

@@ -43,6 +43,8 @@ struct f3
 
 __device__ __forceinline__ f3 F3( float x, float y, float z ) { return f3{ x, y, z }; }
 __device__ __forceinline__ f3 F3( float4 v ) { return f3{ v.x, v.y, v.z }; }
+__device__ __forceinline__ f3 F3( Packed3 v ) { return f3{ v.x, v.y, v.z }; }
+__device__ __forceinline__ Packed3 P3( f3 v ) { return Packed3{ v.x, v.y, v.z }; }
 __device__ __forceinline__ f3 F3( const float* p ) { return f3{ p[0], p[1], p[2] }; }
 __device__ __forceinline__ f3 operator+( f3 a, f3 b ) { return f3{ a.x + b.x, a.y + b.y, a.z + b.z }; }
 __device__ __forceinline__ f3 operator-( f3 a, f3 b ) { return f3{ a.x - b.x, a.y - b.y, a.z - b.z }; }
@@ -963,7 +965,7 @@ __global__ __launch_bounds__( kBlock ) void RaygenKernel( CameraFrame cam, RngPa
         f3 dir = Normalize( aa - position );
         // at bounce 0 the queue is the identity (entry = path id); the origin of every path is the camera and the throughput it
         // starts with 1 (path_tracer.cpp:111, 189): the kernels that read them at bounce 0 know (PathBuffers::origin0)
-        pb.rayD[0][p] = F4( dir, 0.0f );
+        pb.rayD[0][p] = P3( dir );
     }
 }
 
@@ -1127,8 +1129,8 @@ template < bool kSpheres, bool kOrdered >
 __global__ __launch_bounds__( kSpheres ? kTraverseBlock : kTriangleBlock ) __attribute__( ( amdgpu_waves_per_eu( kSpheres ? PT_TRAVERSE_WAVES : PT_TRIANGLE_WAVES, kSpheres ? PT_TRAVERSE_WAVES : PT_TRIANGLE_WAVES ) ) ) void ExtendKernel( SceneView sv, PathBuffers pb, int bounce, uint32_t numPaths, uint64_t* stats )
 {
     UnitStream stream{ pb.cursors + 2 * bounce, bounce == 0 ? nullptr : UnitCount( pb, bounce - 1, kCountNextPaths, 0 ), pb.units, kUnitPaths, numPaths };
-    const float4* rayO = pb.rayO[bounce & 1];
-    const float4* rayD = pb.rayD[bounce & 1];
+    const Packed3* rayO = pb.rayO[bounce & 1];
+    const Packed3* rayD = pb.rayD[bounce & 1];
     const uint32_t end    = kOrdered ? sv.numOrderedNodes : sv.numNodes;
     const SceneBuffers sb = MakeSceneBuffers< kOrdered >( sv );
     __shared__ float4 topLds[kLdsTopNodes > 0 ? 2 * kLdsTopNodes : 1];
@@ -1380,8 +1382,8 @@ void ExtendWideKernel( SceneView sv, PathBuffers pb, int bounce, uint32_t numPat
 {
     constexpr uint32_t kThreads = kSpheres ? kWideSphereBlock : kWideBlock;
     UnitStream stream{ pb.cursors + 2 * bounce, bounce == 0 ? nullptr : UnitCount( pb, bounce - 1, kCountNextPaths, 0 ), pb.units, kUnitPaths, numPaths };
-    const float4* rayO = pb.rayO[bounce & 1];
-    const float4* rayD = pb.rayD[bounce & 1];
+    const Packed3* rayO = pb.rayO[bounce & 1];
+    const Packed3* rayD = pb.rayD[bounce & 1];
     const SceneBuffers sb = MakeWideBuffers( sv );
     // A lane's stack: entries { index of a node's first inner child, its inner slots << 8 | those of them still to visit };
     // the first kWideLdsStack of them in LDS, entry-major
@@ -1589,7 +1591,7 @@ __global__ __launch_bounds__( kConnectBlock ) PT_CONNECT_OCCUPANCY void ConnectK
                     uint32_t entry = pb.shadowSlots == 1 ? rec : rec % entries; // record index = slot * entries + entry
                     asm volatile( "" : "+v"( entry ) );                              // the index first, then both loads in one go
                     float4 dir = pb.shDir[rec];
-                    float4 org = pb.shadowO[entry];
+                    Packed3 org = pb.shadowO[entry];
                     asm volatile( "" : "+v"( dir.x ), "+v"( org.x ) ); // both loads in flight before either is waited for
                     o    = F3( org );
                     d    = F3( dir );
@@ -1755,7 +1757,7 @@ void ConnectWideKernel( SceneView sv, PathBuffers pb, int bounce, uint2* spill, 
                     {
                         asm volatile( "" : "+v"( entry ) );                              // the index first, then both loads in one go
                         float4 dir = pb.shDir[rec];
-                        float4 org = pb.shadowO[entry];
+                        Packed3 org = pb.shadowO[entry];
                         asm volatile( "" : "+v"( dir.x ), "+v"( org.x ) ); // both loads in flight before either is waited for
                         o    = F3( org );
                         d    = F3( dir );
@@ -2457,7 +2459,7 @@ __global__ __launch_bounds__( kBlock ) void ShadeKernel( SceneView sv, RngParams
                     nextT = Tn;
                 }
             }
-            if ( anyShadow ) pb.shadowO[q] = F4( sf.position, 0.0f );
+            if ( anyShadow ) pb.shadowO[q] = P3( sf.position );
         }
         {
             // the path's state for the next bounce goes where its queue entry goes
@@ -2466,9 +2468,9 @@ __global__ __launch_bounds__( kBlock ) void ShadeKernel( SceneView sv, RngParams
             {
                 const uint32_t next = segment + nNext + LanesBelow( mAlive );
                 pb.queue[nxt][next] = p;
-                pb.rayO[nxt][next] = F4( sf.position, 0.0f );
-                pb.rayD[nxt][next] = F4( nextD, 0.0f );
-                pb.thr[nxt][next] = F4( nextT, 0.0f );
+                pb.rayO[nxt][next] = P3( sf.position );
+                pb.rayD[nxt][next] = P3( nextD );
+                pb.thr[nxt][next] = P3( nextT );
             }
             nNext += static_cast< uint32_t >( __popcll( mAlive ) );
         }

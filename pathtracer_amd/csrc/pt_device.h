@@ -116,6 +116,12 @@ struct RngParams
     int32_t tableDraws;
 };
 
+// A vector of the path state as it is stored: three floats, no padding
+struct Packed3
+{
+    float x, y, z;
+};
+
 // Path state of one pass.  What a bounce reads - ray, throughput, closest hit - is indexed by queue position
 // (`entry` = unit * kUnitPaths + position in the unit's segment of the bounce's queue), so the arrays stay dense
 // as paths die; the bounce writes the state of the next one at the positions it appends to.  At bounce 0 the
@@ -123,12 +129,12 @@ struct RngParams
 // its entries too; only the radiance, which outlives the bounces, is indexed by path id.
 struct PathBuffers
 {
-    float4* rayO[2];   // [entry] origin.xyz, double buffered per bounce
-    float4* rayD[2];   // [entry] direction.xyz
-    float4* thr[2];    // [entry] throughput
+    Packed3* rayO[2];  // [entry] origin, double buffered per bounce (12 bytes an entry: the streams of path state are what
+    Packed3* rayD[2];  // [entry] direction                          ShadeKernel's time goes by, and a fourth word would be padding)
+    Packed3* thr[2];   // [entry] throughput
     float4* hit;       // [entry] t, u, v, prim (int bits; -1 = miss)
     float4* rad;       // [path] accumulated radiance of the path
-    float4* shadowO;   // [entry] origin of the path's shadow rays of this bounce
+    Packed3* shadowO;  // [entry] origin of the path's shadow rays of this bounce
     float4* shDir;     // [slot * entries + entry]: wi.xyz, tMax (-1 = no ray, -2 = occluded); entries = units * kUnitPaths
     float4* shEst;     // [slot * entries + entry]: unoccluded contribution; with directSum: throughput * contribution, path id
     uint32_t* queue[2];     // [entry] path id, double buffered per bounce
