@@ -1866,9 +1866,10 @@ void ConnectWideKernel( SceneView sv, PathBuffers pb, int bounce, uint2* spill, 
 // sign of t decides, rightly.  The child passes if byte >= clamp( floor( t ), 0, 256 ).
 __device__ __forceinline__ uint32_t ByteOf( uint32_t w, int k ) { return ( w >> ( 8 * k ) ) & 0xFFu; }
 
-// scheduling of ConnectLightWideKernel, as PT_WIDE_SHADOW_* for ConnectWideKernel
+// scheduling of ConnectLightWideKernel, as PT_WIDE_SHADOW_* for ConnectWideKernel (per launch on a Sponza-class scene:
+// refill at 24 / 32 / 40 idle lanes with bursts of 3: 11.25 / 11.14 / 11.10 ms, bursts of 2 / 3 / 4: 11.32 / 11.14 / 11.29)
 #ifndef PT_LIGHT_WIDE_REFILL_LANES
-#define PT_LIGHT_WIDE_REFILL_LANES 24
+#define PT_LIGHT_WIDE_REFILL_LANES 32
 #endif
 #ifndef PT_LIGHT_WIDE_LEAF_LANES
 #define PT_LIGHT_WIDE_LEAF_LANES 20
@@ -1877,7 +1878,7 @@ __device__ __forceinline__ uint32_t ByteOf( uint32_t w, int k ) { return ( w >> 
 #define PT_LIGHT_WIDE_KEEP_LANES 12
 #endif
 #ifndef PT_LIGHT_WIDE_BURST
-#define PT_LIGHT_WIDE_BURST 2
+#define PT_LIGHT_WIDE_BURST 3
 #endif
 #ifndef PT_LIGHT_WIDE_DEFERRED
 #define PT_LIGHT_WIDE_DEFERRED 2

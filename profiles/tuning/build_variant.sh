@@ -6,7 +6,7 @@
 # scene without spheres), PT_TRAVERSE_BLOCK / PT_TRAVERSE_WAVES (closest hit with the sphere path), PT_CONNECT_BLOCK /
 # PT_CONNECT_WAVES (any hit), PT_WIDE_BLOCK / PT_WIDE_WAVES / PT_WIDE_LDS_STACK / PT_WIDE_REFILL_LANES /
 # PT_WIDE_DEFERRED / PT_WIDE_DEFER_LEAF_LANES / PT_WIDE_DEFER_KEEP_LANES / PT_WIDE_BURST (closest hit over the wide layout),
-# PT_WIDE_SHADOW_REFILL_LANES / _LEAF_LANES / _KEEP_LANES / _DEFERRED / _BURST (any hit over it), PT_UNIT_BATCH (kernels.hip); PT_TOP_NODES is an environment
+# PT_WIDE_SHADOW_REFILL_LANES / _LEAF_LANES / _KEEP_LANES / _DEFERRED / _BURST (any hit over it), PT_LIGHT_WIDE_* likewise (any hit over the wide nodes in the light's frame), PT_UNIT_BATCH (kernels.hip); PT_TOP_NODES is an environment
 # variable read at upload.
 mkdir -p variants/obj
 for f in api bvh_build wide_bvh layout_build; do
