@@ -1405,6 +1405,7 @@ void ExtendWideKernel( SceneView sv, PathBuffers pb, int bounce, uint32_t numPat
     uint32_t entry = kNoRay;
     f3 o = F3( 0.0f, 0.0f, 0.0f ), d = o, invW = o; // invW: WideInv of the reciprocal direction
     bool nx = false, ny = false, nz = false;
+    uint32_t pickRow = 0; // the ray's row of pickLds: its octant << 8
     uint32_t sp = 0;
     uint32_t ambiguous = 0;
     HitRecord h{ FLT_MAX, 0.0f, 0.0f, -1 };
@@ -1444,6 +1445,7 @@ void ExtendWideKernel( SceneView sv, PathBuffers pb, int bounce, uint32_t numPat
                     d   = F3( rayD[entry] );
                     const f3 inv = F3( 1.0f / d.x, 1.0f / d.y, 1.0f / d.z ); // bvh.cpp:235-236
                     nx = inv.x < 0; ny = inv.y < 0; nz = inv.z < 0;
+                    pickRow   = ( nx ? 0x100u : 0u ) | ( ny ? 0x200u : 0u ) | ( nz ? 0x400u : 0u );
                     invW      = WideInv( inv );
                     h         = HitRecord{ FLT_MAX, 0.0f, 0.0f, -1 };     // scene.cpp:372
                     ambiguous = WideDegenerate( inv ) ? kUntrusted : 0u;  // such a ray goes straight to the second pass
@@ -1502,7 +1504,7 @@ void ExtendWideKernel( SceneView sv, PathBuffers pb, int bounce, uint32_t numPat
                 uint2 e = myLds[( top < kWideLdsStack ? top : kWideLdsStack - 1u ) * kThreads];
                 asm volatile( "" : "+v"( e.x ), "+v"( e.y ) ); // the LDS read stays an LDS read
                 if ( top >= kWideLdsStack ) e = spill[( top - kWideLdsStack ) * spillStride + spillLane];
-                const uint32_t s = pickLds[( e.y & 0xFFu ) | ( nx ? 0x100u : 0u ) | ( ny ? 0x200u : 0u ) | ( nz ? 0x400u : 0u )];
+                const uint32_t s = pickLds[( e.y & 0xFFu ) | pickRow];
                 const uint32_t left = e.y & ~( 1u << s );
                 if ( ( left & 0xFFu ) == 0 )
                     sp = top;
