@@ -138,3 +138,17 @@ def test_large_trees(direction):
             reference, fast, ref_stats, st = films(lit_from(hs, 0, direction), 2, 11)
             assert_bits_equal(fast, reference, f"{what}, light {direction}")
             assert ref_stats.rays_shadow > 100000
+
+
+def test_the_wide_nodes_in_the_lights_frame_are_what_ran(scenes):
+    """Shadow rays of a render over the wide layout: over the wide nodes in the light's frame when the scene has them (other
+    node counts than over the wide nodes themselves), the same film either way"""
+    scene = one_directional_light(scenes["cornell"], DIRECTIONS["oblique"])
+    visits, pictures = {}, {}
+    for what, flags in (("light's frame", 0), ("wide nodes", abi.PT_SCENE_NO_PARALLEL_SHADOWS)):
+        with api.DeviceScene(scene.to_desc(flags=flags)) as dev:
+            assert (len(dev.read_layout(abi.PT_LAYOUT_LIGHT_WIDE_NODES)) > 0) == (flags == 0)
+            dev.render(8, seed=4, wide=True, wide_shadows=True)
+            pictures[what], visits[what] = dev.download_film(), dev.stats().nodes_shadow
+    assert_bits_equal(pictures["light's frame"], pictures["wide nodes"], "shadow rays in the light's frame")
+    assert visits["light's frame"] != visits["wide nodes"] and min(visits.values()) > 0
